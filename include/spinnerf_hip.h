@@ -1,0 +1,133 @@
+/* libspinnerf_hip — C ABI of the MI355X-native volumetric-render hot path.
+ *
+ * Drop-in scope: the arithmetic behind DS_NeRF/run_nerf.py's render() / render_rays() /
+ * network_query_fn surface of SamsungLabs/SPIn-NeRF.  The reference has NO native
+ * interface on this path (it is stock torch ops; its only native code, DS_NeRF/torchsearchsorted,
+ * is dead code — SURVEY.md §2 row 5), so each entry point below names the reference *Python*
+ * function whose arithmetic it replaces.  The Python host in spin-nerf_amd/ binds these with
+ * ctypes and reproduces the reference's signatures; INTEGRATION.md shows the stub a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host; tensors are
+ *     contiguous row-major fp32 unless stated; the caller owns all memory (no allocation inside)
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *   - return: 0 = ok, <0 = bad argument (SNR_ERR_*), >0 = hipError_t from the launch
+ *   - re-entrant per stream; no global state
+ */
+#ifndef SPINNERF_HIP_H
+#define SPINNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNR_ABI_VERSION 1
+
+#define SNR_OK 0
+#define SNR_ERR_NULL (-1)         /* a required pointer is NULL */
+#define SNR_ERR_SHAPE (-2)        /* a size is out of the supported range */
+#define SNR_ERR_UNSUPPORTED (-3)  /* configuration not implemented by the HIP path */
+
+#define SNR_PREC_BF16 0 /* bf16 MFMA inputs, fp32 accumulate (v_mfma_f32_32x32x16_bf16) */
+#define SNR_PREC_FP32 1 /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) — the parity mode */
+
+typedef void* snr_stream_t;
+
+/* Shape of one NeRF MLP (DS_NeRF/run_nerf_helpers.py:74-127; built by create_nerf,
+ * run_nerf.py:380-425).  netdepth=8, netwidth=256, skips=[4] are fixed (the reference's
+ * defaults and every BASELINE config); anything else returns SNR_ERR_UNSUPPORTED. */
+typedef struct snr_mlp_config {
+  int multires;       /* --multires, 0..10            (run_nerf.py:383) */
+  int multires_views; /* --multires_views, 0..4       (run_nerf.py:388) */
+  int i_embed;        /* 0 = positional encoding, -1 = identity (helpers:56-57) */
+  int use_viewdirs;   /* --use_viewdirs */
+  int out_ch;         /* output_ch of output_linear when !use_viewdirs (4 or 5, run_nerf.py:390); 4 with viewdirs */
+  int precision;      /* SNR_PREC_* */
+} snr_mlp_config;
+
+int snr_abi_version(void);
+const char* snr_status_string(int status);
+
+/* ---- NeRF MLP: replaces run_network()/network_query_fn + NeRF.forward + their autograd ----
+ * (run_nerf.py:56-71, 427-430; helpers:22-70, 104-127) */
+
+/* number of fp32 parameters, in the reference module's state-dict order (flat buffer layout) */
+int64_t snr_mlp_param_count(const snr_mlp_config* cfg);
+/* bytes of the packed (MFMA fragment order) weight blob produced by snr_mlp_pack */
+int64_t snr_mlp_packed_bytes(const snr_mlp_config* cfg);
+/* bytes of activations snr_mlp_forward saves for backward when `act` != NULL */
+int64_t snr_mlp_act_bytes(const snr_mlp_config* cfg, int64_t n_samples);
+/* bytes of scratch snr_mlp_backward needs */
+int64_t snr_mlp_bwd_ws_bytes(const snr_mlp_config* cfg, int64_t n_samples);
+
+/* flat fp32 parameters -> packed blob (call after every optimizer step) */
+int snr_mlp_pack(const snr_mlp_config* cfg, const float* params, void* packed, snr_stream_t stream);
+
+/* raw[n_samples, out_ch] = NeRF(embed(pts), embed(viewdirs of the sample's ray)).
+ * Sample positions come from `pts` [n_samples,3] if non-NULL, else pts = o + d*z is formed
+ * in-kernel from `rays` (row r = o(3) d(3) ..., leading dimension ray_ld floats) and
+ * `z_vals` [n_rays, samples_per_ray] (run_nerf.py:670-671).  `viewdirs` = n_rays rows of 3 floats
+ * with leading dimension viewdirs_ld (so the last three columns of the packed ray batch can be
+ * passed in place, run_nerf.py:642; required iff use_viewdirs); sample m belongs to ray
+ * m / samples_per_ray (the expand at run_nerf.py:63).
+ * `act` NULL = inference; else snr_mlp_act_bytes() of workspace that backward consumes. */
+int snr_mlp_forward(const snr_mlp_config* cfg, const void* packed, const float* pts, const float* rays,
+                    int ray_ld, const float* z_vals, const float* viewdirs, int viewdirs_ld, int64_t n_samples,
+                    int samples_per_ray, float* raw, void* act, snr_stream_t stream);
+
+/* d(loss)/d(params) from d(loss)/d(raw).  No gradient flows to pts/viewdirs.
+ * grad_params (flat, fp32): overwritten if accumulate == 0, else += . */
+int snr_mlp_backward(const snr_mlp_config* cfg, const void* packed, const float* d_raw, int64_t n_samples,
+                     const void* act, void* ws, float* grad_params, int accumulate, snr_stream_t stream);
+
+/* ---- stratified sampling: replaces run_nerf.py:646-668 ----
+ * z_vals[n_rays, n_samples] from near/far = rays[:,6], rays[:,7]; lindisp per run_nerf.py:647-650;
+ * t_rand [n_rays, n_samples] non-NULL = perturb (run_nerf.py:654-668). */
+int snr_sample_coarse(const float* rays, int ray_ld, int64_t n_rays, int n_samples, int lindisp,
+                      const float* t_rand, float* z_vals, snr_stream_t stream);
+
+/* ---- alpha compositing: replaces raw2outputs (helpers:350-401) ----
+ * raw [n_rays, S, raw_ch] (channels 0..2 rgb, 3 density), z_vals [n_rays,S], rays_d = rays + 3
+ * (leading dimension ray_ld), noise [n_rays,S] pre-scaled or NULL.  Outputs: rgb_map [n,3],
+ * disp_map, acc_map, depth_map [n], weights [n,S], alpha [n,S] or NULL. */
+int snr_composite_forward(const float* raw, int raw_ch, const float* z_vals, const float* rays, int ray_ld,
+                          const float* noise, int64_t n_rays, int S, int white_bkgd, float* rgb_map,
+                          float* disp_map, float* acc_map, float* depth_map, float* weights, float* alpha,
+                          snr_stream_t stream);
+
+/* autograd of the above w.r.t. raw.  Upstream grads may be NULL (= zero).  detach_weights:
+ * rgb_map does not back-propagate into weights (helpers:385-388).  d_raw [n_rays,S,raw_ch] is
+ * fully overwritten (channels >= 4 get 0). */
+int snr_composite_backward(const float* raw, int raw_ch, const float* z_vals, const float* rays, int ray_ld,
+                           const float* noise, int64_t n_rays, int S, int white_bkgd, int detach_weights,
+                           const float* g_rgb, const float* g_disp, const float* g_acc, const float* g_depth,
+                           const float* g_weights, const float* g_alpha, float* d_raw, snr_stream_t stream);
+
+/* ---- hierarchical sampling: replaces sample_pdf + sort + z_std
+ * (helpers:304-347, run_nerf.py:697-702, 726) ----
+ * bins = midpoints of z_coarse, pdf from weights[:,1:-1]; u [n_rays, n_fine] or NULL (= the
+ * deterministic linspace(0,1,n_fine) of det=True).  z_out [n_rays, n_coarse+n_fine] = sorted union,
+ * z_samples [n_rays, n_fine] (may be NULL), z_std [n_rays] = population std of the new samples. */
+int snr_sample_fine(const float* z_coarse, const float* weights, const float* u, int64_t n_rays,
+                    int n_coarse, int n_fine, float* z_out, float* z_samples, float* z_std,
+                    snr_stream_t stream);
+
+/* ---- rays: replaces get_rays + ndc_rays + the ray packing of render() (helpers:249-300,
+ * run_nerf.py:117-153).  Writes rows [o(3) d(3) near far (viewdirs(3))] for the pixel rectangle
+ * [i0,i0+h) x [j0,j0+w) of an H x W pinhole camera with pose c2w_host (12 floats, HOST memory). */
+int snr_make_rays(int H, int W, float focal, const float* c2w_host, int i0, int j0, int h, int w, int ndc,
+                  float near, float far, int use_viewdirs, float* rays, int ray_ld, snr_stream_t stream);
+
+/* ---- Adam on the flat parameter buffer: replaces torch.optim.Adam(lr, betas=(0.9,0.999))
+ * (run_nerf.py:433-434, 1611-1612).  step is 1-based. grad_scale multiplies g first
+ * (1/world_size for data-parallel sums). */
+int snr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int step, float grad_scale, snr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPINNERF_HIP_H */

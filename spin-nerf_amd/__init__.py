@@ -1,0 +1,21 @@
+"""spin-nerf_amd — MI355X-native volumetric renderer, drop-in for the render()/render_rays()/
+network_query_fn surface of SamsungLabs/SPIn-NeRF's DS_NeRF/run_nerf.py.
+
+The directory name carries a hyphen (it mirrors the reference repo's name), so import it either as
+
+    import spin_nerf_amd                      # alias module at the repo root
+    importlib.import_module("spin-nerf_amd")  # the package itself
+"""
+from . import _lib
+from ._lib import HipLibraryError, LIB_PATH
+from .nerf import NeRF
+from .ops import raw2outputs, sample_coarse, sample_fine, make_rays, mlp_query, adam_step_
+from .render import (render, render_rays, batchify_rays, batchify, run_network, create_nerf, get_embedder, get_rays,
+                     ndc_rays, Embedder)
+
+img2mse = lambda x, y: ((x - y) ** 2).mean()                      # helpers:15
+mse2psnr = lambda x: -10. * x.log() / 2.302585092994046           # helpers:17
+
+__all__ = ["NeRF", "render", "render_rays", "batchify_rays", "batchify", "run_network", "create_nerf",
+           "get_embedder", "get_rays", "ndc_rays", "raw2outputs", "sample_coarse", "sample_fine", "make_rays",
+           "mlp_query", "adam_step_", "img2mse", "mse2psnr", "HipLibraryError", "LIB_PATH", "Embedder"]

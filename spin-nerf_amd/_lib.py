@@ -1,0 +1,104 @@
+"""ctypes binding of libspinnerf_hip.so (the C ABI declared in include/spinnerf_hip.h).
+
+There is no CPU fallback: every wrapper raises if the library is missing or a call fails.
+Tensors are passed as raw device pointers; the launch goes on torch's current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspinnerf_hip.so")
+
+PREC_BF16, PREC_FP32 = 0, 1
+
+_c = ctypes
+_p = _c.c_void_p
+_i = _c.c_int
+_l = _c.c_int64
+_f = _c.c_float
+
+
+class MlpConfig(_c.Structure):
+    _fields_ = [("multires", _i), ("multires_views", _i), ("i_embed", _i), ("use_viewdirs", _i),
+                ("out_ch", _i), ("precision", _i)]
+
+    def key(self):
+        return (self.multires, self.multires_views, self.i_embed, self.use_viewdirs, self.out_ch, self.precision)
+
+
+_CFG = _c.POINTER(MlpConfig)
+
+# name -> (restype, argtypes); mirrors include/spinnerf_hip.h one to one
+SIGNATURES = {
+    "snr_abi_version": (_i, []),
+    "snr_status_string": (_c.c_char_p, [_i]),
+    "snr_mlp_param_count": (_l, [_CFG]),
+    "snr_mlp_packed_bytes": (_l, [_CFG]),
+    "snr_mlp_act_bytes": (_l, [_CFG, _l]),
+    "snr_mlp_bwd_ws_bytes": (_l, [_CFG, _l]),
+    "snr_mlp_pack": (_i, [_CFG, _p, _p, _p]),
+    "snr_mlp_forward": (_i, [_CFG, _p, _p, _p, _i, _p, _p, _i, _l, _i, _p, _p, _p]),
+    "snr_mlp_backward": (_i, [_CFG, _p, _p, _l, _p, _p, _p, _i, _p]),
+    "snr_sample_coarse": (_i, [_p, _i, _l, _i, _i, _p, _p, _p]),
+    "snr_composite_forward": (_i, [_p, _i, _p, _p, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "snr_composite_backward": (_i, [_p, _i, _p, _p, _i, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "snr_sample_fine": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p, _p]),
+    "snr_make_rays": (_i, [_i, _i, _f, _c.POINTER(_f), _i, _i, _i, _i, _i, _f, _f, _i, _p, _i, _p]),
+    "snr_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Fails loudly: the product path has no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). spin-nerf_amd has no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.snr_abi_version() != 1:
+        raise HipLibraryError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().snr_status_string(int(status)).decode()
+        raise HipLibraryError(f"{what} failed: {msg} (status {status})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be a contiguous fp32/raw CUDA tensor."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError("spin-nerf_amd kernels need device (HIP) tensors; got a CPU tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32c(t):
+    """contiguous fp32 view/copy"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

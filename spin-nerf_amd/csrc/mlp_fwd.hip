@@ -1,0 +1,377 @@
+// Fused positional-encoding + 8x256 NeRF MLP forward for gfx950, and the weight pack kernel.
+//
+// Replaces run_network()/NeRF.forward of the reference (DS_NeRF/run_nerf.py:56-71,
+// DS_NeRF/run_nerf_helpers.py:22-70, 104-127).  See mlp_layout.h for the data layout and
+// DESIGN.md for the roofline.
+//
+// Workgroup = 4 waves (one per SIMD, up to 512 VGPR+AGPR each); each wave owns a tile of 32
+// samples and carries its activations in registers through all 11 linear layers (the C tile of
+// layer i is, after bias/ReLU/convert, directly the B operand of layer i+1).  The weights of one
+// 32-neuron output tile ("chunk", KS KiB) are DMA'd global->LDS (global_load_lds_dwordx4) into a
+// two-slot ring shared by the 4 waves, one chunk ahead of the MFMAs that consume them.
+#include <type_traits>
+
+#include "snr_common.h"
+#include "mlp_pack.h"
+#include "mlp_device.h"
+
+namespace snr {
+
+// ------------------------------------------------------------------------------------------
+// pack kernel: one thread per (frag, lane) = 16 bytes of the blob
+// ------------------------------------------------------------------------------------------
+template <int P>
+__global__ void mlp_pack_kernel(PackTable T, const float* __restrict__ params, char* __restrict__ blob) {
+  using Frag = typename Mma<P>::Frag;
+  constexpr int EPF = Prec<P>::EPF;
+  const int total_frags = T.fwd_frags + T.bwd_frags;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int F = (int)(gid >> 6), lane = (int)(gid & 63);
+  if (F < total_frags) {
+    int ei = 0;
+    while (ei + 1 < T.n_entries && T.e[ei + 1].frag_begin <= F) ++ei;
+    const PackEntry& E = T.e[ei];
+    const int per_tile = E.src[0].ks + E.src[1].ks;
+    const int local = F - E.frag_begin;
+    const int tile = local / per_tile;
+    int f = local % per_tile;
+    const int s = f >= E.src[0].ks ? 1 : 0;
+    if (s) f -= E.src[0].ks;
+    const PackSrc& S = E.src[s];
+    const int i = lane & 31, g = lane >> 5;
+    const int row = 32 * tile + i;
+    Frag out = Mma<P>::zero();
+#pragma unroll
+    for (int e = 0; e < EPF; ++e) {
+      int slot;  // column (forward) or weight row (dgrad) this k-slot stands for; -1 = padding
+      if (S.kind == SRC_ENC_PTS) slot = enc_slot_feature<P>(f, g, e, T.multires);
+      else if (S.kind == SRC_ENC_DIR) slot = enc_slot_feature<P>(f, g, e, T.multires_views);
+      else if (S.kind == SRC_H) slot = h_slot_neuron<P>(f, g, e);
+      else {  // SRC_OUT: bf16 slot 8g+e, fp32 slot 2e+g  -> raw channel
+        slot = (P == kBF16) ? 8 * g + e : 2 * e + g;
+      }
+      float v = 0.f;
+      if (row < E.rows_valid && slot >= 0) {
+        if (!E.transposed) {
+          v = params[S.w_off + (int64_t)row * S.ld + S.col_off + slot];
+        } else {
+          const int n = slot - S.slot_off;
+          if (n >= 0 && n < S.n_valid) v = params[S.w_off + (int64_t)n * S.ld + S.col_off + row];
+        }
+      }
+      Mma<P>::set(out, e, v);
+    }
+    *(Frag*)(blob + ((int64_t)F * 64 + lane) * 16) = out;
+  }
+  // biases (fp32, true order, zero padded) live behind the frags
+  float* bias = (float*)(blob + (int64_t)total_frags * 1024);
+  if (gid < T.bias_floats) {
+    float v = 0.f;
+    for (int b = 0; b < T.n_bias; ++b) {
+      const int r = (int)gid - T.b[b].dst;
+      if (r >= 0 && r < T.b[b].count) v = r < T.b[b].n_valid ? params[T.b[b].src + r] : 0.f;
+    }
+    bias[gid] = v;
+  }
+}
+
+struct FwdArgs {
+  const char* blob;        // packed weights (forward section first)
+  const float* bias;       // bias block inside the blob
+  int bias_floats;
+  const float* pts;        // [n,3] or null
+  const float* rays;       // rows o(3) d(3) ...
+  int ray_ld;
+  const float* z_vals;     // [n_rays, S]
+  const float* viewdirs;   // n_rays rows of 3, leading dimension vd_ld
+  int vd_ld;
+  int64_t n_samples;
+  int S;
+  int multires, multires_views;
+  int out_ch;
+  float* raw;
+  char* act;               // null = inference
+};
+
+template <int P, bool VD, bool TRAIN>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
+  using B = Blob<P>;
+  using M = Mma<P>;
+  using Frag = typename M::Frag;
+  constexpr int FPT = Prec<P>::FPT;
+  constexpr int KS_H = B::KS_H, KS_PE = B::KS_PE, KS_DIR = B::KS_DIR, KS_H9 = B::KS_H9;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_lds = (float*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, g = lane >> 5;
+
+  for (int i = tid; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
+
+  Pipe<P> pipe;
+  pipe.slots = smem + kBiasLdsBytes;
+  pipe.gbase = pipe.gcur = a.blob;
+  pipe.slot = 0; pipe.wave = wave; pipe.lane = lane;
+  pipe.issue_into(0, KS_PE);  // chunk 0 of stage 0
+
+  const ActLayout<P> AL(a.n_samples, VD);
+  const int64_t n_wg = AL.n_tiles / 4;
+  auto nop = []() {};
+
+  for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
+    const bool more = wg + gridDim.x < n_wg;
+    const int64_t tile = wg * 4 + wave;
+    const int64_t m = tile * 32 + j;
+    const bool valid = m < a.n_samples;
+    const int64_t ray = valid ? m / a.S : 0;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (valid) {
+      if (a.pts) {
+        x = a.pts[3 * m]; y = a.pts[3 * m + 1]; z = a.pts[3 * m + 2];
+      } else {
+        const float* r = a.rays + ray * a.ray_ld;
+        const float t = a.z_vals[m];
+        // run_nerf.py:670-671; separate multiply and add (no FMA) so pts round like the reference's
+        x = mul_add_unfused(r[3], t, r[0]);
+        y = mul_add_unfused(r[4], t, r[1]);
+        z = mul_add_unfused(r[5], t, r[2]);
+      }
+    }
+    Frag pe[KS_PE];
+    encode<P, KS_PE>(x, y, z, a.multires, g, pe);
+    Frag dir[VD ? KS_DIR : 1];
+    if constexpr (VD) {
+      float dx = 0.f, dy = 0.f, dz = 0.f;
+      if (valid) {
+        const float* v = a.viewdirs + ray * a.vd_ld;
+        dx = v[0]; dy = v[1]; dz = v[2];
+      }
+      encode<P, KS_DIR>(dx, dy, dz, a.multires_views, g, dir);
+    }
+
+    // per-lane byte offset inside a [tile][ks][32][32B] section
+    auto act_store = [&](int64_t sec_off, int ks, const Frag* src, int n) {
+      char* base = a.act + sec_off + (tile * ks) * 1024 + g * 16;
+#pragma unroll
+      for (int f = 0; f < 16 * 4; ++f)
+        if (f < n) *(Frag*)(base + f * 1024 + act_row<P>(j, f) * 32) = src[f];
+    };
+
+    Frag hA[KS_H], hB[KS_H];
+    u32x4 mask = {0, 0, 0, 0};
+
+    // ---- generic 8-tile stage: dst = relu(W [sa|sb] + b) ----
+    auto stage8 = [&](auto KA_, auto KB_, const Frag* sa, const Frag* sb, Frag* dst, int bias_off, int next_ks,
+                      bool relu, auto&& pre) {
+      constexpr int KA = decltype(KA_)::value, KB = decltype(KB_)::value;
+      mask = u32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        f32x16 acc = bias_tile(bias_lds, bias_off + 32 * nt, g);
+        if (nt == 0) acc = pipe.template step<KA, KB>(acc, sa, sb, KA + KB, false, pre);
+        else acc = pipe.template step<KA, KB>(acc, sa, sb, nt == 7 ? next_ks : KA + KB, false, nop);
+        if (relu) {
+          unsigned bits = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            bits |= (acc[r] > 0.f ? 1u : 0u) << r;
+            acc[r] = fmaxf(acc[r], 0.f);
+          }
+          if constexpr (TRAIN) mask[nt >> 1] |= bits << (16 * (nt & 1));
+        }
+        acc_to_frags<P>(acc, dst + nt * FPT);
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IPE = std::integral_constant<int, KS_PE>;
+    using IH = std::integral_constant<int, KS_H>;
+    using IDIR = std::integral_constant<int, KS_DIR>;
+
+    auto mask_store = [&](int64_t sec_off, const u32x4& mk) {
+      *(u32x4*)(a.act + sec_off + tile * 1024 + lane * 16) = mk;
+    };
+
+    // stage 0: PE -> hA
+    stage8(IPE{}, I0{}, pe, pe, hA, bias_off_stage(0), KS_H, true, [&]() {
+      if constexpr (TRAIN) {
+        act_store(AL.off_pe(), KS_PE, pe, KS_PE);
+        if constexpr (VD) act_store(AL.off_dir(), KS_DIR, dir, KS_DIR);
+      }
+    });
+    // stages 1..7 ping-pong hA/hB; stage 5 prepends the encoding (skip connection, helpers:110-111)
+    auto pre_of = [&](int s_prev, const Frag* src) {
+      const u32x4 pmask = mask;
+      return [&, s_prev, src, pmask]() {
+        if constexpr (TRAIN) {
+          act_store(AL.off_h(s_prev), KS_H, src, KS_H);
+          mask_store(AL.off_mask(s_prev), pmask);
+        }
+      };
+    };
+    for (int it = 0; it < 2; ++it) {  // stages (1,2), (3,4)
+      const int s1 = 1 + 2 * it;
+      stage8(I0{}, IH{}, hA, hA, hB, bias_off_stage(s1), KS_H, true, pre_of(s1 - 1, hA));
+      stage8(I0{}, IH{}, hB, hB, hA, bias_off_stage(s1 + 1), it == 1 ? KS_PE + KS_H : KS_H, true, pre_of(s1, hB));
+    }
+    stage8(IPE{}, IH{}, pe, hA, hB, bias_off_stage(5), KS_H, true, pre_of(4, hA));
+    stage8(I0{}, IH{}, hB, hB, hA, bias_off_stage(6), KS_H, true, pre_of(5, hB));
+    stage8(I0{}, IH{}, hA, hA, hB, bias_off_stage(7), KS_H, true, pre_of(6, hA));
+    Frag* cur = hB;
+    Frag* nxt = hA;
+    // cur = h7 (hB), nxt = hA
+    const u32x4 mask7 = mask;
+    if constexpr (VD) {
+      // stage 8: feature (8 tiles, no relu) + alpha tile
+      stage8(I0{}, IH{}, cur, cur, nxt, kBiasFeat, KS_H, false, [&]() {
+        if constexpr (TRAIN) { act_store(AL.off_h(7), KS_H, cur, KS_H); mask_store(AL.off_mask(7), mask7); }
+      });
+      f32x16 acc_a = bias_tile(bias_lds, kBiasAlphaTile, g);
+      acc_a = pipe.template step<0, KS_H>(acc_a, cur, cur, KS_H + KS_DIR, false, nop);
+      const float alpha = acc_a[0];  // row 0 lives in register 0 of lanes 0..31
+      // stage 9: views = relu(W [feat | dir] + b), 4 tiles -> h9 (in `cur` storage)
+      Frag* feat = nxt;
+      Frag* h9 = cur;
+      mask = u32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        f32x16 acc = bias_tile(bias_lds, kBiasViews + 32 * nt, g);
+        if (nt == 0)
+          acc = pipe.template step<KS_H, KS_DIR>(acc, feat, dir, KS_H + KS_DIR, false, [&]() {
+            if constexpr (TRAIN) act_store(AL.off_feat(), KS_H, feat, KS_H);
+          });
+        else acc = pipe.template step<KS_H, KS_DIR>(acc, feat, dir, nt == 3 ? KS_H9 : KS_H + KS_DIR, false, nop);
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          bits |= (acc[r] > 0.f ? 1u : 0u) << r;
+          acc[r] = fmaxf(acc[r], 0.f);
+        }
+        if constexpr (TRAIN) mask[nt >> 1] |= bits << (16 * (nt & 1));
+        acc_to_frags<P>(acc, h9 + nt * FPT);
+      }
+      // stage 10: rgb
+      f32x16 acc_c = bias_tile(bias_lds, kBiasRgb, g);
+      const u32x4 mask9 = mask;
+      acc_c = pipe.template step<0, KS_H9>(acc_c, h9, h9, more ? KS_PE : 0, more, [&]() {
+        if constexpr (TRAIN) { act_store(AL.off_h9(), KS_H9, h9, KS_H9); mask_store(AL.off_mask9(), mask9); }
+      });
+      if (valid && g == 0) *(f32x4*)(a.raw + 4 * m) = f32x4{acc_c[0], acc_c[1], acc_c[2], alpha};
+    } else {
+      f32x16 acc_o = bias_tile(bias_lds, kBiasOut, g);
+      acc_o = pipe.template step<0, KS_H>(acc_o, cur, cur, more ? KS_PE : 0, more, [&]() {
+        if constexpr (TRAIN) { act_store(AL.off_h(7), KS_H, cur, KS_H); mask_store(AL.off_mask(7), mask7); }
+      });
+      // rows 0..3 = registers 0..3 of lane half 0; row 4 = register 0 of lane half 1
+      if (valid) {
+        float* o = a.raw + (int64_t)a.out_ch * m;
+        if (g == 0) { o[0] = acc_o[0]; o[1] = acc_o[1]; o[2] = acc_o[2]; o[3] = acc_o[3]; }
+        else if (a.out_ch == 5) o[4] = acc_o[0];
+      }
+    }
+  }
+}
+
+}  // namespace snr
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+using namespace snr;
+
+static int check_cfg(const snr_mlp_config* c) {
+  if (!c) return SNR_ERR_NULL;
+  if (c->precision != SNR_PREC_BF16 && c->precision != SNR_PREC_FP32) return SNR_ERR_UNSUPPORTED;
+  if (c->i_embed != 0 && c->i_embed != -1) return SNR_ERR_UNSUPPORTED;
+  if (c->multires < 0 || c->multires > kMaxMultires) return SNR_ERR_UNSUPPORTED;
+  if (c->multires_views < (c->use_viewdirs ? 0 : -1) || c->multires_views > kMaxMultiresViews)
+    return SNR_ERR_UNSUPPORTED;
+  if (c->use_viewdirs) { if (c->out_ch != 4) return SNR_ERR_UNSUPPORTED; }
+  else if (c->out_ch != 4 && c->out_ch != 5) return SNR_ERR_UNSUPPORTED;
+  return SNR_OK;
+}
+
+template <int P> static PackTable table_of(const snr_mlp_config* c) {
+  return make_pack_table<P>(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
+}
+
+extern "C" int64_t snr_mlp_param_count(const snr_mlp_config* c) {
+  if (check_cfg(c) != SNR_OK) return check_cfg(c);
+  return make_param_layout(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1).total;
+}
+
+extern "C" int64_t snr_mlp_packed_bytes(const snr_mlp_config* c) {
+  if (check_cfg(c) != SNR_OK) return check_cfg(c);
+  const PackTable T = c->precision == SNR_PREC_BF16 ? table_of<kBF16>(c) : table_of<kFP32>(c);
+  return (int64_t)(T.fwd_frags + T.bwd_frags) * 1024 + (int64_t)T.bias_floats * 4;
+}
+
+extern "C" int64_t snr_mlp_act_bytes(const snr_mlp_config* c, int64_t n) {
+  if (check_cfg(c) != SNR_OK) return check_cfg(c);
+  if (n <= 0) return SNR_ERR_SHAPE;
+  return c->precision == SNR_PREC_BF16 ? ActLayout<kBF16>(n, c->use_viewdirs).bytes()
+                                       : ActLayout<kFP32>(n, c->use_viewdirs).bytes();
+}
+
+extern "C" int snr_mlp_pack(const snr_mlp_config* c, const float* params, void* packed, snr_stream_t stream) {
+  int st = check_cfg(c);
+  if (st != SNR_OK) return st;
+  SNR_CHECK_ARG(params && packed, SNR_ERR_NULL);
+  hipStream_t s = (hipStream_t)stream;
+  if (c->precision == SNR_PREC_BF16) {
+    const PackTable T = table_of<kBF16>(c);
+    const int64_t threads = (int64_t)(T.fwd_frags + T.bwd_frags) * 64;
+    mlp_pack_kernel<kBF16><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s>>>(T, params, (char*)packed);
+  } else {
+    const PackTable T = table_of<kFP32>(c);
+    const int64_t threads = (int64_t)(T.fwd_frags + T.bwd_frags) * 64;
+    mlp_pack_kernel<kFP32><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s>>>(T, params, (char*)packed);
+  }
+  return launch_status();
+}
+
+template <int P, bool VD, bool TRAIN>
+static int launch_fwd(const FwdArgs& a, int64_t n_wg, hipStream_t s) {
+  const int lds = kBiasLdsBytes + 2 * Pipe<P>::SLOT;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<P, VD, TRAIN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int64_t grid = n_wg < 1024 ? n_wg : 1024;  // persistent-lite: 4 waves/CU -> 256 resident, stride the rest
+  mlp_fwd_kernel<P, VD, TRAIN><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+  return launch_status();
+}
+
+extern "C" int snr_mlp_forward(const snr_mlp_config* c, const void* packed, const float* pts, const float* rays,
+                               int ray_ld, const float* z_vals, const float* viewdirs, int viewdirs_ld,
+                               int64_t n_samples, int samples_per_ray, float* raw, void* act,
+                               snr_stream_t stream) {
+  int st = check_cfg(c);
+  if (st != SNR_OK) return st;
+  SNR_CHECK_ARG(packed && raw, SNR_ERR_NULL);
+  SNR_CHECK_ARG(pts || (rays && z_vals), SNR_ERR_NULL);
+  SNR_CHECK_ARG(!c->use_viewdirs || (viewdirs && viewdirs_ld >= 3), SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_samples > 0 && samples_per_ray > 0, SNR_ERR_SHAPE);
+  SNR_CHECK_ARG(pts || ray_ld >= 6, SNR_ERR_SHAPE);
+  const bool bf = c->precision == SNR_PREC_BF16;
+  const PackTable T = bf ? table_of<kBF16>(c) : table_of<kFP32>(c);
+  FwdArgs a{};
+  a.blob = (const char*)packed;
+  a.bias = (const float*)((const char*)packed + (int64_t)(T.fwd_frags + T.bwd_frags) * 1024);
+  a.bias_floats = T.bias_floats;
+  a.pts = pts; a.rays = rays; a.ray_ld = ray_ld; a.z_vals = z_vals; a.viewdirs = viewdirs; a.vd_ld = viewdirs_ld;
+  a.n_samples = n_samples; a.S = samples_per_ray;
+  a.multires = T.multires; a.multires_views = T.multires_views; a.out_ch = c->out_ch;
+  a.raw = raw; a.act = (char*)act;
+  const int64_t n_wg = (n_samples + 127) / 128;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vd = c->use_viewdirs, tr = act != nullptr;
+#define SNR_FWD(P_) \
+  (vd ? (tr ? launch_fwd<P_, true, true>(a, n_wg, s) : launch_fwd<P_, true, false>(a, n_wg, s)) \
+      : (tr ? launch_fwd<P_, false, true>(a, n_wg, s) : launch_fwd<P_, false, false>(a, n_wg, s)))
+  return bf ? SNR_FWD(kBF16) : SNR_FWD(kFP32);
+#undef SNR_FWD
+}

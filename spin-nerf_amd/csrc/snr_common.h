@@ -1,0 +1,65 @@
+// Shared device/host helpers for libspinnerf_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/spinnerf_hip.h"
+#include "mlp_layout.h"
+
+namespace snr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define SNR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+
+// 0 = ok, <0 = bad argument, >0 = hipError_t  (include/spinnerf_hip.h)
+#define SNR_CHECK_ARG(cond, code) \
+  do {                            \
+    if (!(cond)) return (code);   \
+  } while (0)
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SNR_OK : (int)e;
+}
+
+// ---- MFMA policies --------------------------------------------------------------------------
+template <int P> struct Mma;
+
+template <> struct Mma<kBF16> {
+  using Frag = bf16x8;
+  static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  // frag h of a C tile = registers 8h..8h+7, rounded to bf16 (RNE, v_cvt_pk_bf16_f32)
+  template <int H> static __device__ __forceinline__ Frag from_acc(const f32x16& v) {
+    f32x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = v[8 * H + e];
+    return __builtin_convertvector(t, Frag);
+  }
+  static __device__ __forceinline__ Frag zero() { return Frag{0, 0, 0, 0, 0, 0, 0, 0}; }
+  static __device__ __forceinline__ void set(Frag& f, int e, float x) { f[e] = (__bf16)x; }
+  static __device__ __forceinline__ float get(const Frag& f, int e) { return (float)f[e]; }
+};
+
+template <> struct Mma<kFP32> {
+  using Frag = f32x4;
+  static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], c, 0, 0, 0);
+    return c;
+  }
+  template <int H> static __device__ __forceinline__ Frag from_acc(const f32x16& v) {
+    return Frag{v[4 * H], v[4 * H + 1], v[4 * H + 2], v[4 * H + 3]};
+  }
+  static __device__ __forceinline__ Frag zero() { return Frag{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ void set(Frag& f, int e, float x) { f[e] = x; }
+  static __device__ __forceinline__ float get(const Frag& f, int e) { return f[e]; }
+};
+
+}  // namespace snr

@@ -1,0 +1,192 @@
+"""torch.autograd bindings of the HIP kernels (one Function per C-ABI forward/backward pair).
+
+Every function here enqueues work on torch's current HIP stream through ``_lib`` and allocates its
+outputs/workspaces with torch's caching allocator; there is no eager/PyTorch fallback.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, f32c, ptr, stream
+
+
+# ----------------------------------------------------------------------------------------------
+# stratified sampling (run_nerf.py:646-668)
+# ----------------------------------------------------------------------------------------------
+def sample_coarse(ray_batch, N_samples, lindisp=False, t_rand=None):
+    """z_vals [N_rays, N_samples] from near/far = ray_batch[:, 6:8]; ``t_rand`` = perturb draws."""
+    lib = _lib.load()
+    rays = f32c(ray_batch)
+    n = rays.shape[0]
+    z = torch.empty(n, N_samples, device=rays.device, dtype=torch.float32)
+    tr = f32c(t_rand) if t_rand is not None else None
+    check(lib.snr_sample_coarse(ptr(rays), rays.shape[1], n, N_samples, int(bool(lindisp)), ptr(tr), ptr(z),
+                                stream()), "snr_sample_coarse")
+    return z
+
+
+# ----------------------------------------------------------------------------------------------
+# hierarchical sampling (helpers:304-347 + run_nerf.py:697-702, 726)
+# ----------------------------------------------------------------------------------------------
+def sample_fine(z_coarse, weights, N_importance, u=None):
+    """-> (z_vals sorted union [N, Nc+Nf], z_samples [N, Nf], z_std [N]).  ``u`` None = det linspace.
+    Outputs are detached by construction (the reference detaches z_samples, run_nerf.py:700)."""
+    lib = _lib.load()
+    zc, w = f32c(z_coarse.detach()), f32c(weights.detach())
+    n, nc = zc.shape
+    z_out = torch.empty(n, nc + N_importance, device=zc.device, dtype=torch.float32)
+    z_s = torch.empty(n, N_importance, device=zc.device, dtype=torch.float32)
+    z_std = torch.empty(n, device=zc.device, dtype=torch.float32)
+    uu = f32c(u) if u is not None else None
+    check(lib.snr_sample_fine(ptr(zc), ptr(w), ptr(uu), n, nc, N_importance, ptr(z_out), ptr(z_s), ptr(z_std),
+                              stream()), "snr_sample_fine")
+    return z_out, z_s, z_std
+
+
+# ----------------------------------------------------------------------------------------------
+# alpha compositing (helpers:350-401)
+# ----------------------------------------------------------------------------------------------
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays, noise, white_bkgd, detach_weights, need_alpha):
+        lib = _lib.load()
+        raw_c, z, r = f32c(raw), f32c(z_vals), f32c(rays)
+        n, S, C = raw_c.shape
+        dev = raw_c.device
+        rgb = torch.empty(n, 3, device=dev)
+        disp = torch.empty(n, device=dev)
+        acc = torch.empty(n, device=dev)
+        depth = torch.empty(n, device=dev)
+        w = torch.empty(n, S, device=dev)
+        alpha = torch.empty(n, S, device=dev) if need_alpha else None
+        nz = f32c(noise) if noise is not None else None
+        check(lib.snr_composite_forward(ptr(raw_c), C, ptr(z), ptr(r), r.shape[1], ptr(nz), n, S,
+                                        int(bool(white_bkgd)), ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(w),
+                                        ptr(alpha), stream()), "snr_composite_forward")
+        ctx.save_for_backward(raw_c, z, r, nz)
+        ctx.flags = (int(bool(white_bkgd)), int(bool(detach_weights)), need_alpha)
+        return rgb, disp, acc, depth, w, alpha
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_w, g_alpha):
+        lib = _lib.load()
+        raw, z, r, nz = ctx.saved_tensors
+        white, detach, need_alpha = ctx.flags
+        n, S, C = raw.shape
+        d_raw = torch.empty_like(raw)
+        gs = [f32c(g) if g is not None else None for g in (g_rgb, g_disp, g_acc, g_depth, g_w, g_alpha)]
+        check(lib.snr_composite_backward(ptr(raw), C, ptr(z), ptr(r), r.shape[1], ptr(nz), n, S, white, detach,
+                                         ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]),
+                                         ptr(gs[5]) if need_alpha else None, ptr(d_raw), stream()),
+              "snr_composite_backward")
+        return d_raw, None, None, None, None, None, None
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, need_alpha=False,
+                detach_weights=False, noise=None, rays=None):
+    """Same signature and 6-tuple as the reference's raw2outputs (helpers:350-401):
+    (rgb_map, disp_map, acc_map, weights, depth_map, alpha|None).
+
+    ``noise`` (pre-scaled, [N,S]) overrides the random draw; ``pytest`` reproduces the reference's
+    numpy seed-0 *uniform* draw (helpers:377-380).  ``rays`` may carry the packed ray rows so that
+    rays_d is read in place."""
+    import numpy as np
+    if noise is None and raw_noise_std > 0.:
+        if pytest:
+            np.random.seed(0)
+            noise = torch.Tensor(np.random.rand(*list(raw[..., 3].shape)) * raw_noise_std).to(raw.device)
+        else:
+            noise = torch.randn(raw[..., 3].shape, device=raw.device) * raw_noise_std
+    if rays is None:
+        rays = torch.cat([torch.zeros_like(rays_d), rays_d], -1)
+    rgb, disp, acc, depth, w, alpha = _Composite.apply(raw, z_vals, rays, noise, white_bkgd, detach_weights,
+                                                       need_alpha)
+    return rgb, disp, acc, w, depth, alpha
+
+
+# ----------------------------------------------------------------------------------------------
+# rays (helpers:249-300)
+# ----------------------------------------------------------------------------------------------
+def make_rays(H, W, focal, c2w, patch=None, ndc=True, near=0., far=1., use_viewdirs=False, device=None):
+    """Packed ray rows [h*w, 8 or 11] = o d near far (viewdirs) for a full frame or a patch
+    (run_nerf.py:117-153 fused with get_rays / ndc_rays)."""
+    import ctypes
+    lib = _lib.load()
+    c = torch.as_tensor(c2w, dtype=torch.float32).detach().cpu()[:3, :4].contiguous()
+    arr = (ctypes.c_float * 12)(*c.reshape(-1).tolist())
+    i0, j0, h, w = (0, 0, H, W) if patch is None else patch
+    ld = 11 if use_viewdirs else 8
+    rays = torch.empty(h * w, ld, device=device or torch.device("cuda"), dtype=torch.float32)
+    check(lib.snr_make_rays(int(H), int(W), float(focal), arr, int(i0), int(j0), int(h), int(w), int(bool(ndc)),
+                            float(near), float(far), int(bool(use_viewdirs)), ptr(rays), ld, stream()),
+          "snr_make_rays")
+    return rays
+
+
+# ----------------------------------------------------------------------------------------------
+# NeRF MLP (run_nerf.py:56-71; helpers:104-127)
+# ----------------------------------------------------------------------------------------------
+class _Mlp(torch.autograd.Function):
+    """raw = MLP(flat_params; sample positions, view directions).  Gradient flows to the flat
+    parameter buffer only (nothing upstream of the encodings needs one)."""
+
+    @staticmethod
+    def forward(ctx, flat, net, pts, rays, z_vals, viewdirs, n_samples, S):
+        lib = _lib.load()
+        cfg = net.cfg
+        packed = net.packed_weights()
+        raw = torch.empty(n_samples, cfg.out_ch, device=flat.device, dtype=torch.float32)
+        need_grad = ctx.needs_input_grad[0]
+        act = None
+        if need_grad:
+            nbytes = lib.snr_mlp_act_bytes(cfg, n_samples)
+            act = torch.empty(nbytes, device=flat.device, dtype=torch.uint8)
+        vd_ld = viewdirs.stride(0) if viewdirs is not None else 0
+        check(lib.snr_mlp_forward(cfg, ptr(packed), ptr(pts), ptr(rays), rays.shape[1] if rays is not None else 0,
+                                  ptr(z_vals), ptr(viewdirs), vd_ld, n_samples, S, ptr(raw), ptr(act), stream()),
+              "snr_mlp_forward")
+        ctx.net, ctx.n_samples = net, n_samples
+        ctx.act, ctx.packed = act, packed
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        lib = _lib.load()
+        net, n = ctx.net, ctx.n_samples
+        cfg = net.cfg
+        g = torch.empty_like(net.flat)
+        ws = torch.empty(lib.snr_mlp_bwd_ws_bytes(cfg, n), device=g.device, dtype=torch.uint8)
+        check(lib.snr_mlp_backward(cfg, ptr(ctx.packed), ptr(f32c(d_raw)), n, ptr(ctx.act), ptr(ws), ptr(g), 0,
+                                   stream()), "snr_mlp_backward")
+        ctx.act = None
+        return g, None, None, None, None, None, None, None
+
+
+def mlp_query(net, pts=None, rays=None, z_vals=None, viewdirs=None, samples_per_ray=1):
+    """Low-level entry: either ``pts`` [M,3] or (``rays`` rows + ``z_vals`` [N,S]).  ``viewdirs`` is a
+    [N,>=3] (possibly strided) view whose first three columns are the unit directions."""
+    if pts is not None:
+        pts = f32c(pts.detach())
+        M = pts.shape[0]
+    else:
+        rays, z_vals = f32c(rays.detach()), f32c(z_vals.detach())
+        M = z_vals.numel()
+        samples_per_ray = z_vals.shape[1]
+    if net.cfg.use_viewdirs:
+        if viewdirs is None:
+            raise ValueError("this network was built with use_viewdirs=True; viewdirs is required")
+        viewdirs = viewdirs.detach()
+        if viewdirs.dtype != torch.float32 or viewdirs.stride(-1) != 1:
+            viewdirs = f32c(viewdirs)
+    else:
+        viewdirs = None
+    return _Mlp.apply(net.flat, net, pts, rays, z_vals, viewdirs, M, samples_per_ray)
+
+
+# ----------------------------------------------------------------------------------------------
+# Adam on a flat buffer (run_nerf.py:433-434)
+# ----------------------------------------------------------------------------------------------
+def adam_step_(params, grads, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    lib = _lib.load()
+    check(lib.snr_adam_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), params.numel(), float(lr),
+                            float(beta1), float(beta2), float(eps), int(step), float(grad_scale), stream()),
+          "snr_adam_step")

@@ -1,0 +1,356 @@
+"""Host-side mirror of the reference's render surface (DS_NeRF/run_nerf.py:44-165, 380-496, 593-737).
+
+Same function names, positional/keyword arguments, return structure (list of four maps + extras
+dict), dict keys and error behaviour as the reference; the arithmetic runs in the HIP kernels of
+libspinnerf_hip (no torch fallback).  Two additions, both optional keyword arguments that the
+reference does not have:
+
+  randoms=   dict(t_rand, u, noise_c, noise_f) of explicit random draws for parity tests
+             (the reference can only inject randomness through its numpy-seeded ``pytest=`` hook,
+             which is supported too and reproduces the same numbers);
+  precision= on create_nerf's args (``args.precision`` = 'bf16' | 'fp32', default 'bf16').
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .nerf import NeRF
+
+DEBUG = False
+
+
+# ----------------------------------------------------------------------------------------------
+# embedders (helpers:22-70) — the encoding itself is fused into the MLP kernel
+# ----------------------------------------------------------------------------------------------
+class Embedder:
+    """Descriptor of a positional encoding: ``out_dim`` = 3 + 6*multires (helpers:43-49).
+    The sin/cos evaluation happens inside the fused kernel, so this object is only a shape carrier."""
+
+    def __init__(self, multires, identity=False):
+        self.multires = 0 if identity else multires
+        self.identity = identity
+        self.out_dim = 3 if identity else 3 + 6 * multires
+
+    def __call__(self, x):
+        raise NotImplementedError("positional encoding is fused into the HIP MLP kernel; call network_query_fn / "
+                                  "NeRF.query instead of embedding on the host")
+
+
+def get_embedder(multires, i=0):
+    """-> (embed descriptor, out_dim); i == -1 is the identity (helpers:55-70)."""
+    e = Embedder(multires, identity=(i == -1))
+    return e, e.out_dim
+
+
+# ----------------------------------------------------------------------------------------------
+# run_network / batchify (run_nerf.py:44-71)
+# ----------------------------------------------------------------------------------------------
+def batchify(fn, chunk):
+    """Kept for API parity (run_nerf.py:44-53).  The fused kernel streams samples, so chunking is
+    only applied when the caller insists on a chunk smaller than the input."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+
+    return ret
+
+
+def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk=1024 * 64):
+    """Prepares inputs and applies network 'fn' (run_nerf.py:56-71): inputs [N,S,3], viewdirs [N,3]
+    or None -> [N,S,out_ch].  Flatten/embed/expand/cat are fused into the kernel; ``netchunk`` does
+    not change results (run_nerf.py:100-101) and is ignored."""
+    if viewdirs is not None and not fn.use_viewdirs:
+        viewdirs = None
+    return fn.query(inputs, viewdirs)
+
+
+# ----------------------------------------------------------------------------------------------
+# render_rays (run_nerf.py:593-737)
+# ----------------------------------------------------------------------------------------------
+def _pytest_rand(shape, device):
+    np.random.seed(0)                                        # run_nerf.py:664-666
+    return torch.Tensor(np.random.rand(*shape)).to(device)
+
+
+def render_rays(ray_batch,
+                network_fn,
+                network_query_fn,
+                N_samples,
+                retraw=False,
+                lindisp=False,
+                perturb=0.,
+                N_importance=0,
+                network_fine=None,
+                white_bkgd=False,
+                raw_noise_std=0.,
+                pytest=False,
+                sigma_loss=None,
+                verbose=False,
+                need_alpha=False,
+                detach_weights=False,
+                randoms=None):
+    """Volumetric rendering of one chunk of rays; returns the reference's dict (run_nerf.py:715-731)."""
+    randoms = randoms or {}
+    N_rays = ray_batch.shape[0]
+    dev = ray_batch.device
+    ray_batch = ray_batch.float().contiguous()
+    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
+    viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 9 else None      # run_nerf.py:642
+    near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
+
+    # stratified samples (run_nerf.py:646-668)
+    t_rand = None
+    if perturb > 0.:
+        t_rand = randoms.get("t_rand")
+        if t_rand is None:
+            t_rand = _pytest_rand([N_rays, N_samples], dev) if pytest else torch.rand(N_rays, N_samples, device=dev)
+    z_vals = ops.sample_coarse(ray_batch, N_samples, lindisp, t_rand)
+
+    fused = getattr(network_query_fn, "_snr_fused", False)
+
+    def query(z, net):
+        if fused:   # pts = o + d z is formed inside the kernel (run_nerf.py:670-671)
+            return net.query_rays(ray_batch, z, viewdirs if net.use_viewdirs else None)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+        return network_query_fn(pts, viewdirs, net)
+
+    def noise_for(key, S):
+        if raw_noise_std <= 0.:
+            return None
+        n = randoms.get(key)
+        if n is not None:
+            return n
+        if pytest:                                            # helpers:377-380 (uniform, not normal)
+            return _pytest_rand([N_rays, S], dev) * raw_noise_std
+        return torch.randn(N_rays, S, device=dev) * raw_noise_std
+
+    def composite(raw, z, noise):
+        rgb, disp, acc, depth, w, alpha = ops._Composite.apply(raw, z, ray_batch, noise, white_bkgd, detach_weights,
+                                                               need_alpha)
+        return rgb, disp, acc, w, depth, alpha
+
+    if network_fn is not None:                                # run_nerf.py:674-692
+        coarse_net = network_fn
+    elif getattr(network_fine, "alpha_model", None) is not None:
+        coarse_net = network_fine.alpha_model
+    else:
+        coarse_net = network_fine
+    raw = query(z_vals, coarse_net)
+    rgb_map, disp_map, acc_map, weights, depth_map, alpha = composite(raw, z_vals, noise_for("noise_c", N_samples))
+
+    if N_importance > 0:                                      # run_nerf.py:694-713
+        rgb_map_0, disp_map_0, acc_map_0, alpha0 = rgb_map, disp_map, acc_map, alpha
+        u = randoms.get("u")
+        if u is None and perturb > 0.:
+            u = _pytest_rand([N_rays, N_importance], dev) if pytest else torch.rand(N_rays, N_importance, device=dev)
+        elif u is None and pytest:                            # helpers:322-327: float64 linspace cast to fp32
+            u = torch.Tensor(np.broadcast_to(np.linspace(0., 1., N_importance), (N_rays, N_importance)).copy()).to(dev)
+        z_vals, z_samples, z_std = ops.sample_fine(z_vals, weights, N_importance, u)
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = query(z_vals, run_fn)
+        rgb_map, disp_map, acc_map, weights, depth_map, alpha = composite(
+            raw, z_vals, noise_for("noise_f", N_samples + N_importance))
+
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map, 'depth_map': depth_map,
+           'weights': weights, 'z_vals': z_vals}
+    if retraw:
+        ret['raw'] = raw
+    if need_alpha:
+        ret['alpha'] = alpha
+        ret['alpha0'] = alpha0   # NameError when N_importance == 0, exactly like run_nerf.py:721
+    if N_importance > 0:
+        ret['rgb0'] = rgb_map_0
+        ret['disp0'] = disp_map_0
+        ret['acc0'] = acc_map_0
+        ret['z_std'] = z_std                                  # run_nerf.py:726
+
+    if sigma_loss is not None and ray_batch.shape[-1] > 11:   # run_nerf.py:728-731
+        depths = ray_batch[:, 8]
+        ret['sigma_loss'] = sigma_loss.calculate_loss(rays_o, rays_d, viewdirs, near, far, depths, network_query_fn,
+                                                      network_fine)
+
+    if DEBUG:
+        for k in ret:
+            if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
+                print(f"! [Numerical Error] {k} contains nan or inf.")
+    return ret
+
+
+# ----------------------------------------------------------------------------------------------
+# batchify_rays / render (run_nerf.py:74-165)
+# ----------------------------------------------------------------------------------------------
+def batchify_rays(rays_flat, chunk=1024 * 32, need_alpha=False, detach_weights=False, **kwargs):
+    """Render rays in smaller minibatches (run_nerf.py:74-87).  Results do not depend on chunk."""
+    randoms = kwargs.pop("randoms", None)
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        rnd = None
+        if randoms:
+            rnd = {k: (v[i:i + chunk] if v is not None else None) for k, v in randoms.items()}
+        ret = render_rays(rays_flat[i:i + chunk], need_alpha=need_alpha, detach_weights=detach_weights,
+                          randoms=rnd, **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+
+
+def get_rays(H, W, focal, c2w):
+    """(rays_o, rays_d) [H,W,3] each (helpers:249-260), produced by the ray kernel."""
+    dev = c2w.device if isinstance(c2w, torch.Tensor) and c2w.is_cuda else torch.device("cuda")
+    r = ops.make_rays(H, W, focal, c2w, ndc=False, use_viewdirs=False, device=dev)
+    return r[:, 0:3].reshape(H, W, 3), r[:, 3:6].reshape(H, W, 3)
+
+
+def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True,
+           near=0., far=1.,
+           use_viewdirs=False, c2w_staticcam=None, depths=None, need_alpha=False, detach_weights=False,
+           patch=None,
+           **kwargs):
+    """Render rays (run_nerf.py:90-165) -> [rgb_map, disp_map, acc_map, depth_map, extras]."""
+    if c2w is not None and c2w_staticcam is None and depths is None and not isinstance(near, torch.Tensor):
+        # full frame / patch: rays, viewdirs (before NDC), the NDC warp and the packing in one kernel
+        dev = c2w.device if isinstance(c2w, torch.Tensor) and c2w.is_cuda else torch.device("cuda")
+        if patch is not None:
+            i, j, len1, len2 = patch
+            pr = (i, j, min(len1, H - i), min(len2, W - j))
+        else:
+            pr = None
+        rays_flat = ops.make_rays(H, W, focal, c2w, patch=pr, ndc=ndc, near=float(near), far=float(far),
+                                  use_viewdirs=use_viewdirs, device=dev)
+        sh = (pr[2], pr[3], 3) if pr is not None else (H, W, 3)
+    else:
+        if c2w is not None:
+            rays_o, rays_d = get_rays(H, W, focal, c2w)
+            if patch is not None:
+                i, j, len1, len2 = patch
+                rays_o = rays_o[i:i + len1, j:j + len2, :]
+                rays_d = rays_d[i:i + len1, j:j + len2, :]
+        else:
+            rays_o, rays_d = rays
+        if use_viewdirs:
+            viewdirs = rays_d
+            if c2w_staticcam is not None:
+                rays_o, rays_d = get_rays(H, W, focal, c2w_staticcam)
+            viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+            viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+        sh = rays_d.shape
+        if ndc:
+            rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
+        rays_o = torch.reshape(rays_o, [-1, 3]).float()
+        rays_d = torch.reshape(rays_d, [-1, 3]).float()
+        near_t, far_t = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+        cols = [rays_o, rays_d, near_t, far_t]
+        if depths is not None:
+            cols.append(depths.reshape(-1, 1))
+        if use_viewdirs:
+            cols.append(viewdirs)
+        rays_flat = torch.cat(cols, -1)
+
+    all_ret = batchify_rays(rays_flat, chunk, need_alpha=need_alpha, detach_weights=detach_weights, **kwargs)
+    for k in all_ret:
+        k_sh = list(sh[:-1]) + list(all_ret[k].shape[1:])
+        all_ret[k] = torch.reshape(all_ret[k], k_sh)
+
+    k_extract = ['rgb_map', 'disp_map', 'acc_map', 'depth_map']
+    ret_list = [all_ret[k] for k in k_extract]
+    ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
+    return ret_list + [ret_dict]
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """NDC warp of caller-provided ray tensors (helpers:283-300).  Element-wise ray preparation on
+    tensors the caller already holds in HBM; full frames go through the ray kernel instead."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    o0 = -1. / (W / (2. * focal)) * rays_o[..., 0] / rays_o[..., 2]
+    o1 = -1. / (H / (2. * focal)) * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1. + 2. * near / rays_o[..., 2]
+    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2. * near / rays_o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+# ----------------------------------------------------------------------------------------------
+# create_nerf (run_nerf.py:380-496)
+# ----------------------------------------------------------------------------------------------
+def create_nerf(args, device=None):
+    """Instantiate the coarse/fine MLPs, the query closure, Adam and the render kwargs — same return
+    tuple as the reference: (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer)."""
+    device = device or torch.device("cuda")
+    precision = getattr(args, "precision", None)
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    input_ch_views = 0
+    embeddirs_fn = None
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    skips = [4]
+    if getattr(args, "alpha_model_path", None) is not None:
+        raise NotImplementedError("--alpha_model_path (NeRF_RGB, helpers:159-216) is outside the HIP path's scope")
+    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, precision=precision).to(device)
+    grad_vars = list(model.parameters())
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
+                          skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs,
+                          precision=precision).to(device)
+        grad_vars += list(model_fine.parameters())
+
+    def network_query_fn(inputs, viewdirs, network_fn):
+        return run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                           netchunk=args.netchunk)
+    network_query_fn._snr_fused = True   # lets render_rays form pts in-kernel instead of materialising them
+
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+
+    start = 0
+    basedir, expname = args.basedir, args.expname
+    if getattr(args, "ft_path", None) is not None and args.ft_path != 'None':
+        ckpts = [args.ft_path]
+    else:
+        ckpts = [os.path.join(basedir, expname, f) for f in sorted(os.listdir(os.path.join(basedir, expname)))
+                 if 'tar' in f]
+    print('Found ckpts', ckpts)
+    if len(ckpts) > 0 and not args.no_reload:
+        ckpt_path = ckpts[-1]
+        print('Reloading from', ckpt_path)
+        ckpt = torch.load(ckpt_path, map_location=device)
+        start = ckpt['global_step']
+        try:
+            optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+        except (ValueError, KeyError):
+            # a reference checkpoint stores per-layer Adam moments; this build keeps one flat buffer
+            print('optimizer state of a per-layer checkpoint not restored (flat-parameter layout)')
+        model.load_state_dict(ckpt['network_fn_state_dict'])
+        if model_fine is not None:
+            model_fine.load_state_dict(ckpt['network_fine_state_dict'])
+
+    render_kwargs_train = {
+        'network_query_fn': network_query_fn,
+        'perturb': args.perturb,
+        'N_importance': args.N_importance,
+        'network_fine': model_fine,
+        'N_samples': args.N_samples,
+        'network_fn': model,
+        'use_viewdirs': args.use_viewdirs,
+        'white_bkgd': args.white_bkgd,
+        'raw_noise_std': args.raw_noise_std,
+    }
+    if args.dataset_type != 'llff' or args.no_ndc:           # run_nerf.py:478-483
+        print('Not ndc!')
+        render_kwargs_train['ndc'] = False
+        render_kwargs_train['lindisp'] = args.lindisp
+    else:
+        render_kwargs_train['ndc'] = True
+    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+    if getattr(args, "sigma_loss", False):
+        raise NotImplementedError("--sigma_loss (loss.py:8-44) is outside the HIP path's scope (off in every config)")
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer

@@ -1,0 +1,312 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): every HIP kernel, called through the C ABI
+bindings of ``spin-nerf_amd``, against the CPU oracle and the reference-generated golden fixtures.
+
+Tolerances (fp32 unless stated) follow SURVEY.md §8(d) "Parity gates": rgb/acc atol 1e-5,
+depth/disp rtol 1e-4, weights/z_vals atol 1e-4; the bf16 MLP is held against the oracle's
+bf16-rounding emulation (same rounding points, fp32 accumulate).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from helpers import (load, T, mlp_case_params, MLP_CASES, R2O_CASES, PDF_CASES)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import spin_nerf_amd as S
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    S._lib.load()
+    return S
+
+
+def dev(t):
+    return t.cuda() if t is not None else None
+
+
+def close(a, b, atol=1e-6, rtol=1e-5, msg=""):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol, err_msg=msg)
+
+
+def make_net(S, sd, vd, precision, out_ch=4):
+    net = S.NeRF(input_ch=63, input_ch_views=27 if vd else 0, use_viewdirs=vd, output_ch=out_ch,
+                 precision=precision).cuda()
+    net.load_state_dict(sd)
+    return net
+
+
+# ---------------------------------------------------------------------------------------------
+# fused PE + MLP forward
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", MLP_CASES)
+def test_mlp_forward_fp32_matches_reference(S, name):
+    g = load(name)
+    vd = bool(g["use_viewdirs"])
+    sd = mlp_case_params(g)
+    net = make_net(S, sd, vd, "fp32", out_ch=4 if vd else 5)
+    with torch.no_grad():
+        out = net.query(dev(T(g["pts"]))[:, None, :], dev(T(g["dirs"])) if vd else None)[:, 0]
+    # golden = the reference module's own output on the same inputs
+    close(out, g["out"], atol=2e-5, rtol=2e-5)
+    # reference calling convention: forward(cat(embedded pts, embedded dirs))
+    with torch.no_grad():
+        out2 = net(dev(T(g["x"])))
+    close(out2, g["out"], atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("name", MLP_CASES)
+def test_mlp_forward_bf16_matches_bf16_emulation(S, name):
+    g = load(name)
+    vd = bool(g["use_viewdirs"])
+    sd = mlp_case_params(g)
+    net = make_net(S, sd, vd, "bf16", out_ch=4 if vd else 5)
+    with torch.no_grad():
+        out = net.query(dev(T(g["pts"]))[:, None, :], dev(T(g["dirs"])) if vd else None)[:, 0]
+    emu = O.nerf_forward_bf16emu(sd, T(g["x"]), input_ch_views=27 if vd else 0, use_viewdirs=vd)
+    scale = float(emu.abs().max())
+    # same rounding points; residual = fp32 summation order flipping an occasional bf16 rounding
+    close(out, emu, atol=1.5e-2 * max(scale, 1.0), rtol=0)
+    # and the stated bf16-vs-fp32 gap: 2^-8 relative per activation over 10 layers
+    close(out, g["out"], atol=6e-2 * max(scale, 1.0), rtol=0)
+
+
+def test_mlp_forward_many_tiles_and_ray_form(S):
+    """n_samples not a multiple of the 128-sample workgroup, several workgroups per CU slot, and
+    the (rays, z_vals) entry point that forms pts in-kernel."""
+    sd = O.make_wild_params(seed=3)
+    net = make_net(S, sd, True, "fp32")
+    rs = np.random.RandomState(0)
+    n_rays, Sps = 37, 23
+    rays = torch.from_numpy(rs.normal(size=(n_rays, 11)).astype(np.float32))
+    rays[:, 8:11] = torch.nn.functional.normalize(rays[:, 8:11], dim=-1)
+    z = torch.sort(torch.from_numpy(rs.uniform(0.5, 4, size=(n_rays, Sps)).astype(np.float32)), -1)[0]
+    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
+    ref = O.run_network(sd, pts, rays[:, 8:11])
+    with torch.no_grad():
+        out = net.query_rays(rays.cuda(), z.cuda(), rays.cuda()[:, -3:])
+        out_pts = net.query(pts.cuda(), rays.cuda()[:, 8:11])
+    # pts formed in-kernel use fma-contracted o + d*z: allow the 1-ulp input difference amplified by 2^9 frequencies
+    close(out_pts, ref, atol=5e-5, rtol=5e-5)
+    close(out, ref, atol=5e-3, rtol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# raw2outputs
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", R2O_CASES)
+def test_composite_forward_backward(S, name):
+    g = load(name)
+    raw = dev(T(g["raw"])).requires_grad_(True)
+    noise = dev(T(g["noise"])) if g["noise"].size else None
+    rgb, disp, acc, w, depth, alpha = S.raw2outputs(raw, dev(T(g["z"])), dev(T(g["d"])), white_bkgd=bool(g["white"]),
+                                                    need_alpha=True, detach_weights=bool(g["detach"]), noise=noise)
+    close(rgb, g["rgb"], atol=1e-5); close(acc, g["acc"], atol=1e-5)
+    close(w, g["w"], atol=1e-5); close(alpha, g["alpha"], atol=1e-5)
+    close(depth, g["depth"], rtol=1e-4, atol=1e-5); close(disp, g["disp"], rtol=1e-4, atol=1e-5)
+    loss = ((dev(T(g["g_rgb"])) * rgb).sum() + (dev(T(g["g_disp"])) * disp).sum() + (dev(T(g["g_acc"])) * acc).sum()
+            + (dev(T(g["g_w"])) * w).sum() + (dev(T(g["g_depth"])) * depth).sum())
+    loss.backward()
+    ref = g["d_raw"]
+    scale = np.abs(ref).max()
+    close(raw.grad / scale, ref / scale, atol=2e-5, rtol=1e-3)
+
+
+def test_composite_need_alpha_false_returns_none(S):
+    g = load("r2o_s64")
+    out = S.raw2outputs(dev(T(g["raw"])), dev(T(g["z"])), dev(T(g["d"])))
+    assert out[5] is None and len(out) == 6
+
+
+# ---------------------------------------------------------------------------------------------
+# sampling
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lindisp", [False, True])
+@pytest.mark.parametrize("perturb", [False, True])
+@pytest.mark.parametrize("N", [64, 7, 1])
+def test_sample_coarse(S, lindisp, perturb, N):
+    rs = np.random.RandomState(1)
+    n = 50
+    rays = torch.zeros(n, 11)
+    rays[:, 6] = torch.from_numpy(rs.uniform(0.5, 2.0, n).astype(np.float32))
+    rays[:, 7] = rays[:, 6] + torch.from_numpy(rs.uniform(0.5, 8.0, n).astype(np.float32))
+    t_rand = torch.from_numpy(rs.uniform(size=(n, N)).astype(np.float32)) if perturb else None
+    ref = O.sample_z(rays[:, 6:7], rays[:, 7:8], N, lindisp, t_rand)
+    out = S.sample_coarse(rays.cuda(), N, lindisp, dev(t_rand))
+    close(out, ref, atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", PDF_CASES)
+def test_sample_fine_matches_sample_pdf(S, name):
+    """bins/weights in the fixtures are free-form; feed the kernel a z_coarse whose midpoints are
+    the fixture's bins and weights padded by one on each side (the [1:-1] slice, run_nerf.py:699)."""
+    g = load(name)
+    bins, w, u = T(g["bins"]), T(g["w"]), T(g["u"])
+    n, nb = bins.shape
+    # z_coarse with mid(z)[i] == bins[i]: z0 free, z_{i+1} = 2 bins_i - z_i  (fp64 to keep it exact-ish)
+    z = torch.zeros(n, nb + 1, dtype=torch.float64)
+    z[:, 0] = bins[:, 0].double() - 0.01
+    for i in range(nb):
+        z[:, i + 1] = 2 * bins[:, i].double() - z[:, i]
+    zc = z.float()
+    mids = .5 * (zc[:, 1:] + zc[:, :-1])
+    wfull = torch.cat([torch.zeros(n, 1), w, torch.zeros(n, 1)], -1)
+    ref_samples = O.sample_pdf(mids, w, u.shape[1], det=bool(g["det"]), u=u)
+    z_out, z_s, z_std = S.sample_fine(zc.cuda(), wfull.cuda(), u.shape[1], u.cuda())
+    close(z_s, ref_samples, atol=2e-5, rtol=1e-5)
+    if float((mids - bins).abs().max()) < 1e-6:
+        close(z_s, g["out"], atol=2e-5, rtol=1e-5)   # the reference's own output
+    ref_sorted = torch.sort(torch.cat([zc, ref_samples], -1), -1)[0]
+    close(z_out, ref_sorted, atol=2e-5, rtol=1e-5)
+    assert bool((z_out[:, 1:] >= z_out[:, :-1]).all())
+    close(z_std, torch.std(ref_samples, dim=-1, unbiased=False), atol=1e-5, rtol=1e-4)
+    if bool(g["det"]):
+        z_out2, z_s2, _ = S.sample_fine(zc.cuda(), wfull.cuda(), u.shape[1], None)
+        close(z_s2, ref_samples, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,A,V", [(1, 3, 1), (100, 50, 12), (200, 500, 120)])
+def test_sample_fine_bin_search_grid_from_searchsorted_tests(S, B, A, V):
+    """The reference's only pytest suite (DS_NeRF/torchsearchsorted/test/test_searchsorted.py:27-44)
+    sweeps a batched search over B in {1,100,200}, A in {1,50,500}, V in {1,12,120}; the same grid
+    (A >= 3 here: the renderer needs two bins) exercises the kernel's binary search + sort."""
+    rs = np.random.RandomState(B + A + V)
+    zc = torch.sort(torch.from_numpy(rs.uniform(0, 10, size=(B, A)).astype(np.float32)), -1)[0]
+    w = torch.from_numpy(rs.uniform(0, 1, size=(B, A)).astype(np.float32))
+    u = torch.from_numpy(rs.uniform(0, 1, size=(B, V)).astype(np.float32))
+    mids = .5 * (zc[:, 1:] + zc[:, :-1])
+    ref = O.sample_pdf(mids, w[:, 1:-1], V, u=u)
+    z_out, z_s, _ = S.sample_fine(zc.cuda(), w.cuda(), V, u.cuda())
+    close(z_s, ref, atol=1e-4, rtol=1e-4)
+    close(z_out, torch.sort(torch.cat([zc, ref], -1), -1)[0], atol=1e-4, rtol=1e-4)
+
+
+def test_make_rays_and_ndc(S):
+    g = load("rays")
+    H, W, f = int(g["H"]), int(g["W"]), float(g["focal"])
+    ro, rd = S.get_rays(H, W, f, T(g["c2w"]))
+    close(ro, g["rays_o"], atol=0, rtol=0); close(rd, g["rays_d"], atol=1e-6)
+    r = S.make_rays(H, W, f, T(g["c2w"]), ndc=True, near=0., far=1., use_viewdirs=True)
+    close(r[:, 0:3].reshape(H, W, 3), g["ndc_o"], atol=1e-5, rtol=1e-5)
+    close(r[:, 3:6].reshape(H, W, 3), g["ndc_d"], atol=1e-5, rtol=1e-5)
+    vd = T(g["rays_d"]) / torch.norm(T(g["rays_d"]), dim=-1, keepdim=True)
+    close(r[:, 8:11].reshape(H, W, 3), vd, atol=1e-6)
+    no, nd = S.ndc_rays(H, W, f, 1., dev(T(g["rays_o"])), dev(T(g["rays_d"])))
+    close(no, g["ndc_o"], atol=1e-5, rtol=1e-5)
+
+
+def test_adam_matches_torch_adam(S):
+    rs = np.random.RandomState(0)
+    n = 10007
+    p0 = torch.from_numpy(rs.normal(size=n).astype(np.float32))
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=5e-4, betas=(0.9, 0.999))
+    p, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in range(1, 6):
+        gr = torch.from_numpy(rs.normal(size=n).astype(np.float32))
+        p_ref.grad = gr.clone()
+        opt.step()
+        S.adam_step_(p, gr.cuda(), m, v, 5e-4, step)
+    close(p, p_ref, atol=1e-6, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# MLP backward: d loss / d params against autograd through the oracle MLP
+# ---------------------------------------------------------------------------------------------
+def _mlp_grad_case(S, vd, precision, n_rays, sps, seed, wild=True, mlp=O.nerf_forward):
+    out_ch = 4 if vd else 5
+    mk = O.make_wild_params if wild else O.init_nerf_params
+    sd = mk(seed=seed, use_viewdirs=vd, output_ch=out_ch, input_ch_views=27 if vd else 0)
+    for v in sd.values():
+        v.requires_grad_(True)
+    rs = np.random.RandomState(seed)
+    pts = torch.from_numpy(rs.uniform(-2, 2, size=(n_rays, sps, 3)).astype(np.float32))
+    dirs = torch.nn.functional.normalize(torch.from_numpy(rs.normal(size=(n_rays, 3)).astype(np.float32)), dim=-1)
+    d_raw = torch.from_numpy(rs.normal(size=(n_rays, sps, out_ch)).astype(np.float32))
+    ref = O.run_network(sd, pts, dirs if vd else None, use_viewdirs=vd, mlp=mlp)
+    (ref * d_raw).sum().backward()
+    net = make_net(S, {k: v.detach() for k, v in sd.items()}, vd, precision, out_ch=out_ch)
+    out = net.query(pts.cuda(), dirs.cuda() if vd else None)
+    (out * d_raw.cuda()).sum().backward()
+    return sd, net
+
+
+def _rel_l2(a, b):
+    a, b = a.detach().cpu().double().reshape(-1), b.detach().cpu().double().reshape(-1)
+    return float((a - b).norm() / b.norm()), float((a @ b) / (a.norm() * b.norm()))
+
+
+@pytest.mark.parametrize("vd", [True, False])
+def test_mlp_backward_fp32_matches_autograd_elementwise(S, vd):
+    """35 samples: too few for any pre-activation to sit within an ulp of 0, so every gradient element
+    must agree with torch autograd to fp32 rounding."""
+    sd, net = _mlp_grad_case(S, vd, "fp32", 5, 7, seed=5)
+    got = net.named_views(net.flat.grad)
+    for k, p in sd.items():
+        if p.grad is None:   # views_linears.0 without viewdirs is unused (helpers:118-120)
+            assert float(got[k].abs().max()) == 0.0, k
+            continue
+        scale = float(p.grad.abs().max())
+        close(got[k] / scale, p.grad / scale, atol=2e-5, rtol=1e-4, msg=k)
+
+
+@pytest.mark.parametrize("vd", [True, False])
+@pytest.mark.parametrize("n_rays,sps", [(33, 64), (16, 192), (64, 192)])
+def test_mlp_backward_fp32_matches_autograd(S, vd, n_rays, sps):
+    """Multi-tile / multi-split shapes.  Among ~10^7 hidden units a few pre-activations land within an
+    ulp of 0 and take the other ReLU branch than torch's summation order does; one such flip moves the
+    gradients of all earlier layers by ~5e-4 relative (measured: layers above the flip agree to 1e-6).
+    Gate: relative L2 error 3e-3 per tensor."""
+    sd, net = _mlp_grad_case(S, vd, "fp32", n_rays, sps, seed=5)
+    got = net.named_views(net.flat.grad)
+    for k, p in sd.items():
+        if p.grad is None:
+            assert float(got[k].abs().max()) == 0.0, k
+            continue
+        rel, cos = _rel_l2(got[k], p.grad)
+        assert rel < 3e-3, f"{k}: relative L2 error {rel:.2e}"
+
+
+@pytest.mark.parametrize("wild", [False, True])
+@pytest.mark.parametrize("vd", [True, False])
+def test_mlp_backward_bf16(S, vd, wild):
+    """bf16 MFMA inputs (activations, weights, d z), fp32 accumulation.
+
+    vs autograd through the oracle's bf16 emulation (same forward rounding points, hence the same
+    ReLU masks; its casts also round the back-propagated gradients to bf16): relative L2 error per
+    parameter tensor < 5e-2.
+    vs the fp32 reference gradient: the bf16 forward flips ~0.3 % of the ReLU masks per layer, i.e.
+    ~5 % relative L2 per layer compounding to ~15 % at the first layer (measured) — stated gate
+    0.3, cosine > 0.95.  That is the noise floor of ANY bf16-activation ReLU MLP, not of this
+    kernel; training quality is judged by PSNR at equal iterations (tests/test_gpu_train.py)."""
+    sd, net = _mlp_grad_case(S, vd, "bf16", 33, 64, seed=6, wild=wild, mlp=O.nerf_forward_bf16emu)
+    got = net.named_views(net.flat.grad)
+    for k, p in sd.items():
+        if p.grad is None:
+            continue
+        rel, cos = _rel_l2(got[k], p.grad)
+        assert rel < 5e-2, f"{k}: relative L2 error vs bf16 emulation {rel:.2e}"
+    sd32, _ = _mlp_grad_case(S, vd, "bf16", 33, 64, seed=6, wild=wild)
+    for k, p in sd32.items():
+        if p.grad is None:
+            continue
+        rel, cos = _rel_l2(got[k], p.grad)
+        assert rel < 0.3 and cos > 0.95, f"{k}: vs fp32 autograd: relative L2 error {rel:.2e}, cosine {cos:.4f}"
+
+
+def test_mlp_backward_accumulates_over_calls(S):
+    """Three render() calls per reference iteration (run_nerf.py:1455-1470) -> grads add up."""
+    sd = O.make_wild_params(seed=7)
+    net = make_net(S, sd, True, "fp32")
+    rs = np.random.RandomState(7)
+    pts = torch.from_numpy(rs.uniform(-2, 2, size=(9, 16, 3)).astype(np.float32)).cuda()
+    dirs = torch.nn.functional.normalize(torch.from_numpy(rs.normal(size=(9, 3)).astype(np.float32)), dim=-1).cuda()
+    net.query(pts, dirs).sum().backward()
+    g1 = net.flat.grad.clone()
+    net.flat.grad = None
+    (net.query(pts, dirs).sum() + net.query(pts, dirs).sum()).backward()
+    close(net.flat.grad, 2 * g1, atol=1e-6 * float(g1.abs().max()), rtol=1e-5)
