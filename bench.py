@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Benchmark of the render hot path on MI355X: training rays/s (+ ms/frame), roofline, CPU baseline.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus 8 --steps 20 --warmup 5
+
+One "step" = one render() of N_rand rays (64 coarse + 128 fine samples, viewdirs) + mse(rgb)+mse(rgb0)
++ backward + Adam on both MLPs — the step the rays/s metric of BASELINE.json counts.
+Workload = BASELINE.json configs[1] shape: synthetic 378x504 pinhole camera (statue/8), no_ndc +
+lindisp + white_bkgd + raw_noise_std=1 + perturb=1 like the reference's configs/config.txt,
+N_rand = 1024 rays per GPU (weak scaling: config 4's 8192 rays = 1024 x 8), random-init networks,
+inputs resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic MACs per MLP evaluation: forward 593 408; wgrad the same (every weight
+# once); dgrad excludes the three encoding inputs (63*256 + 63*256 + 27*128)
+MAC_FWD = 63 * 256 + 4 * 256 * 256 + 319 * 256 + 2 * 256 * 256 + 256 * 256 + 256 + 283 * 128 + 128 * 3
+MAC_WGRAD = MAC_FWD
+MAC_DGRAD = MAC_FWD - (63 * 256 + 63 * 256 + 27 * 128)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def make_args(ns):
+    return argparse.Namespace(
+        multires=10, multires_views=4, i_embed=0, use_viewdirs=True, N_importance=ns.n_fine, N_samples=ns.n_coarse,
+        alpha_model_path=None, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=1024 * 64,
+        lrate=5e-4, basedir=tempfile.mkdtemp(prefix="snr_bench_"), expname="", ft_path=None, no_reload=True,
+        perturb=1.0, white_bkgd=True, raw_noise_std=1.0, dataset_type="llff", no_ndc=True, lindisp=True,
+        sigma_loss=False, no_coarse=False, precision=ns.precision)
+
+
+def synthetic_batches(n_batches, n_rand, H, W, focal, seed, device):
+    """rays of a 378x504 pinhole camera (identity pose looking down -z), seeded pixel subsets, U[0,1) targets"""
+    import spin_nerf_amd as S
+    c2w = torch.eye(4)[:3, :4]
+    rays_o, rays_d = S.get_rays(H, W, focal, c2w.to(device))
+    rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n_batches):
+        sel = torch.randperm(H * W, generator=g)[:n_rand].to(device)
+        target = torch.rand(n_rand, 3, generator=g).to(device)
+        out.append((torch.stack([rays_o[sel], rays_d[sel]], 0).contiguous(), target))
+    return out
+
+
+def cpu_baseline(ns, H, W, focal, near, far):
+    """The oracle's training step (oracle/nerf_oracle.py, a port of the reference's torch ops) on the
+    host cores — a reported baseline, measured on a bounded sample of the same workload."""
+    from oracle import nerf_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    n_rand = ns.n_rand
+    sd_c = O.init_nerf_params(seed=0)
+    sd_f = O.init_nerf_params(seed=1) if ns.n_fine > 0 else None
+    params = [p.requires_grad_(True) for sd in (sd_c, sd_f) if sd is not None for p in sd.values()]
+    opt = O.AdamState(params, lr=5e-4)
+    c2w = torch.eye(4)[:3, :4]
+    ro, rd = O.get_rays(H, W, focal, c2w)
+    g = torch.Generator().manual_seed(5)
+    kw = dict(H=H, W=W, focal=focal, chunk=1024 * 32, ndc=False, near=near, far=far, use_viewdirs=True,
+              N_samples=ns.n_coarse, N_importance=ns.n_fine, perturb=1.0, white_bkgd=True, lindisp=True)
+    times = []
+    n_steps = 1 + ns.cpu_steps
+    for i in range(n_steps):
+        sel = torch.randperm(H * W, generator=g)[:n_rand]
+        rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+        target = torch.rand(n_rand, 3, generator=g)
+        rnd = dict(t_rand=torch.rand(n_rand, ns.n_coarse), u=torch.rand(n_rand, ns.n_fine) if ns.n_fine else None,
+                   noise_c=torch.randn(n_rand, ns.n_coarse),
+                   noise_f=torch.randn(n_rand, ns.n_coarse + ns.n_fine) if ns.n_fine else None)
+        t0 = time.perf_counter()
+        O.train_step(sd_c, sd_f, opt, rays, target, kw, randoms=rnd)
+        times.append(time.perf_counter() - t0)
+    t = float(np.mean(times[1:]))
+    return {"value": n_rand / t, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{ns.cpu_steps} steps of {n_rand} rays x ({ns.n_coarse}+{ns.n_fine}) samples after 1 warm-up, "
+                      f"fp32 torch CPU ops, {os.cpu_count()} threads, anomaly detection off"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--n-rand", type=int, default=1024, help="rays per GPU per step")
+    ap.add_argument("--n-coarse", type=int, default=64)
+    ap.add_argument("--n-fine", type=int, default=128)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frame", action="store_true")
+    ns = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+    if ns.gpus != world and rank == 0:
+        print(f"warning: --gpus {ns.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    import spin_nerf_amd as S
+    from importlib import import_module
+    RenderTrainer = import_module("spin-nerf_amd.train").RenderTrainer
+
+    H, W, focal, near, far = 378, 504, 400.0, 1.2, 9.0
+    torch.manual_seed(0)
+    args = make_args(ns)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        kw_train, kw_test, start, grad_vars, _ = S.create_nerf(args, device=device)
+    kw_train.update(near=near, far=far)
+    kw_test.update(near=near, far=far)
+    trainer = RenderTrainer(kw_train, lrate=5e-4, lrate_decay=250, world_size=world)
+    trainer.broadcast_parameters()
+
+    n_batches = 8
+    batches = synthetic_batches(n_batches, ns.n_rand, H, W, focal, seed=5 + rank, device=device)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run_steps(n, first):
+        for i in range(n):
+            rays, target = batches[(first + i) % n_batches]
+            trainer.step(H, W, focal, rays, target)
+
+    run_steps(ns.warmup, 0)
+    sync_all()
+    t0 = time.perf_counter()
+    run_steps(ns.steps, ns.warmup)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    rays_per_s = world * ns.n_rand * ns.steps / elapsed
+
+    # ---- per-kernel timing with HIP events on the launch stream: the same K steps again, profiled ----
+    S._lib.prof_enable(True)
+    S._lib.prof_read()
+    torch.cuda.synchronize()
+    tp0 = time.perf_counter()
+    run_steps(ns.steps, ns.warmup)
+    torch.cuda.synchronize()
+    prof_elapsed = time.perf_counter() - tp0
+    prof = S._lib.prof_read()
+    S._lib.prof_enable(False)
+
+    # ---- ms/frame: full 378x504 frame, no_grad, perturb=0, raw_noise_std=0 ----
+    ms_frame = None
+    if not ns.no_frame and rank == 0:
+        c2w = torch.eye(4)[:3, :4].to(device)
+        with torch.no_grad():
+            S.render(H, W, focal, chunk=1024 * 32, c2w=c2w, **kw_test)
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            nf = 3
+            for _ in range(nf):
+                S.render(H, W, focal, chunk=1024 * 32, c2w=c2w, **kw_test)
+            torch.cuda.synchronize()
+            ms_frame = (time.perf_counter() - tf) / nf * 1e3
+
+    if rank != 0:
+        return
+    n_c, n_f = ns.n_rand * ns.n_coarse, ns.n_rand * (ns.n_coarse + ns.n_fine)
+    evals_per_step = n_c + (n_f if ns.n_fine else 0)
+    flops = {"mlp_fwd": 2 * MAC_FWD, "mlp_dgrad": 2 * MAC_DGRAD, "mlp_wgrad": 2 * MAC_WGRAD}
+    kernels = {}
+    for k, (ms, cnt) in prof.items():
+        kernels[k] = {"ms_per_step": ms / ns.steps, "launches_per_step": cnt / ns.steps}
+        if k in flops:
+            # launches alternate coarse (n_c samples) / fine (n_f samples); per-step algorithmic FLOPs / per-step time
+            kernels[k]["tflops"] = flops[k] * evals_per_step / (ms / ns.steps * 1e-3) / 1e12
+    dom = max((k for k in kernels if k in flops), key=lambda k: kernels[k]["ms_per_step"])
+    peak = PEAK_TFLOPS[ns.precision]
+    launches = kernels[dom]["launches_per_step"]
+    roofline = {
+        "kernel": dom, "bound": "mfma",
+        "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kernels[dom]["tflops"] / peak,
+        "traffic": None,
+        "flops_per_launch": flops[dom] * evals_per_step / launches,
+        "avg_launch_ms": kernels[dom]["ms_per_step"] / launches,
+    }
+    step_flops = 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) * evals_per_step
+    out = {
+        "metric": "training rays/sec", "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": ns.steps,
+        "warmup": ns.warmup, "ms_per_step": elapsed / ns.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": ns.precision, "data": "synthetic",
+        "config": {"workload": f"statue-shaped 378x504 pinhole, N_rand={ns.n_rand}/GPU x ({ns.n_coarse}c+{ns.n_fine}f) "
+                               "samples, viewdirs, no_ndc+lindisp+white_bkgd, perturb=1, raw_noise_std=1, "
+                               "render+mse(rgb)+mse(rgb0)+backward+Adam, random-init 8x256 coarse+fine MLPs",
+                   "global_batch_rays": world * ns.n_rand, "parallelism": f"ray-dp{world}"},
+        "ms_per_frame_378x504": ms_frame,
+        "step_tflops_algorithmic": step_flops / (elapsed / ns.steps) / 1e12,
+        "roofline": roofline,
+        "kernels": kernels,
+        "ms_per_step_profiled": prof_elapsed / ns.steps * 1e3,
+    }
+    if not ns.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(ns, H, W, focal, near, far)
+        out["speedup_vs_cpu_baseline"] = rays_per_s / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,15 @@ int snr_make_rays(int H, int W, float focal, const float* c2w_host, int i0, int 
 int snr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int step, float grad_scale, snr_stream_t stream);
 
+/* ---- diagnostics: per-kernel HIP-event timing (used by bench.py for the roofline line) ----
+ * When enabled, every kernel launch of this library is bracketed by hipEvents on its stream;
+ * snr_prof_read() waits for them, returns total elapsed ms and launch count per kernel id
+ * (arrays of snr_prof_kernel_count() entries) and clears the log.  Process-global, off by default. */
+int snr_prof_enable(int on);
+int snr_prof_kernel_count(void);
+const char* snr_prof_kernel_name(int id);
+int snr_prof_read(double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

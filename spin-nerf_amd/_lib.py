@@ -47,6 +47,10 @@ SIGNATURES = {
     "snr_sample_fine": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p, _p]),
     "snr_make_rays": (_i, [_i, _i, _f, _c.POINTER(_f), _i, _i, _i, _i, _i, _f, _f, _i, _p, _i, _p]),
     "snr_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),
+    "snr_prof_enable": (_i, [_i]),
+    "snr_prof_kernel_count": (_i, []),
+    "snr_prof_kernel_name": (_c.c_char_p, [_i]),
+    "snr_prof_read": (_i, [_c.POINTER(_c.c_double), _c.POINTER(_l)]),
 }
 
 _lib = None
@@ -76,6 +80,19 @@ def load():
         raise HipLibraryError("ABI version mismatch")
     _lib = lib
     return lib
+
+
+def prof_enable(on=True):
+    check(load().snr_prof_enable(int(bool(on))), "snr_prof_enable")
+
+
+def prof_read():
+    """{kernel name: (total_ms, launches)} of everything recorded since the last read."""
+    lib = load()
+    n = lib.snr_prof_kernel_count()
+    ms, cnt = (_c.c_double * n)(), (_l * n)()
+    check(lib.snr_prof_read(ms, cnt), "snr_prof_read")
+    return {lib.snr_prof_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}
 
 
 def check(status, what):

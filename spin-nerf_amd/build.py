@@ -19,6 +19,7 @@ SOURCES = [
     ("mlp_fwd.hip", []),
     ("mlp_bwd.hip", []),
     ("render_ops.hip", ["-ffp-contract=off"]),
+    ("prof.cpp", ["-x", "hip"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
@@ -47,7 +48,7 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
             continue
-        o = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        o = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
             cmd = [_hipcc()] + COMMON + extra + ["-c", s, "-o", o]

@@ -22,31 +22,16 @@
 #include "snr_common.h"
 #include "mlp_pack.h"
 #include "mlp_device.h"
+#include "mlp_wgrad.h"
 
 namespace snr {
-
-// ------------------------------------------------------------------------------------------
-// backward scratch: d z sections ([n_tiles][ks KiB], like ActLayout) followed by wgrad partials
-// ------------------------------------------------------------------------------------------
-template <int P> struct WsLayout {
-  using B = Blob<P>;
-  int64_t n_tiles;
-  int vd;
-  SNR_HD WsLayout(int64_t n_samples, int vd_) : n_tiles(((n_samples + 127) / 128) * 4), vd(vd_) {}
-  SNR_HD int64_t off_dout() const { return 0; }
-  SNR_HD int64_t off_dz(int i) const { return n_tiles * 1024 * (1 + (int64_t)i * B::KS_H); }  // i in 0..7
-  SNR_HD int64_t off_dfeat() const { return n_tiles * 1024 * (1 + 8 * (int64_t)B::KS_H); }
-  SNR_HD int64_t off_dz9() const { return off_dfeat() + n_tiles * 1024 * B::KS_H; }
-  SNR_HD int64_t dz_bytes() const {
-    return n_tiles * 1024 * (1 + 8 * (int64_t)B::KS_H + (vd ? B::KS_H + B::KS_H9 : 0));
-  }
-};
 
 // ------------------------------------------------------------------------------------------
 // 1. dgrad chain
 // ------------------------------------------------------------------------------------------
 struct DgradArgs {
-  const char* blob_bwd;   // dgrad chunks (behind the forward section)
+  const char* blob_bwd;   // dgrad blocks (behind the forward section)
+  int bwd_blocks;
   const float* d_raw;     // [n, out_ch]
   int64_t n_samples;
   int out_ch;
@@ -69,10 +54,7 @@ __global__ __launch_bounds__(256) void mlp_dgrad_kernel(DgradArgs a) {
 
   constexpr int FIRST_KS = 1;  // both variants start with the OUT frag
   Pipe<P> pipe;
-  pipe.slots = smem;
-  pipe.gbase = pipe.gcur = a.blob_bwd;
-  pipe.slot = 0; pipe.wave = wave; pipe.lane = lane;
-  pipe.issue_into(0, FIRST_KS);
+  pipe.init(smem, a.blob_bwd, a.bwd_blocks, wave, lane);
 
   const ActLayout<P> AL(a.n_samples, VD);
   const WsLayout<P> WL(a.n_samples, VD);
@@ -118,8 +100,8 @@ __global__ __launch_bounds__(256) void mlp_dgrad_kernel(DgradArgs a) {
       for (int nt = 0; nt < NT; ++nt) {
         f32x16 acc = zero16;
         const bool last = nt == NT - 1;
-        if (nt == 0) acc = pipe.template step<KA, KB>(acc, sa, sb, last ? next_ks : KA + KB, last && wrap_last, pre);
-        else acc = pipe.template step<KA, KB>(acc, sa, sb, last ? next_ks : KA + KB, last && wrap_last, nop);
+        if (nt == 0) acc = pipe.template step<KA, KB>(acc, sa, sb, 0, pre);
+        else acc = pipe.template step<KA, KB>(acc, sa, sb, nt * (KA + KB), nop);
         if (use_mask) {
           const unsigned bits = mk_cur[nt >> 1] >> (16 * (nt & 1));
 #pragma unroll
@@ -167,303 +149,7 @@ __global__ __launch_bounds__(256) void mlp_dgrad_kernel(DgradArgs a) {
     stage(IH{}, I0{}, I8{}, hB, hB, hA, true, more ? FIRST_KS : 0, more, [&]() { ws_store(WL.off_dz(1), KS_H, hB, KS_H); });
     ws_store(WL.off_dz(0), KS_H, hA, KS_H);
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// 2. wgrad (split-K over samples)
-// ------------------------------------------------------------------------------------------
-struct WgradJob {
-  int64_t a_off, b_off;     // byte offsets of the [n_tiles][ks KiB] sections (A in ws, B in act)
-  int a_ks, b_ks;           // KiB per tile
-  int nta, ntb;             // 32-row / 32-column output tiles
-  int a_kind, b_kind;       // SrcKind of the k-slot order (for the reduce scatter)
-  int w_off, ld, col_off;   // destination weight matrix
-  int row_off, rows_valid;  // OUT sources: weight row = channel - row_off
-  int cols_valid;           // valid true columns of the B side
-  int bias_off;             // destination bias or -1
-  int split_begin, n_splits;
-  int64_t part_off;         // float offset of this job's partials [n_splits][nta*32][ntb*32] (+ bias [n_splits][nta*32])
-  int64_t bias_part_off;
-};
-constexpr int kMaxJobs = 16;
-struct WgradArgs {
-  int n_jobs;
-  WgradJob job[kMaxJobs];
-  const char* act;
-  const char* ws;
-  float* part;
-  int64_t n_tiles;
-  int L_pts, L_dir;
-};
-
-template <int P> struct WgradCfg;
-template <> struct WgradCfg<kBF16> { static constexpr int TILES_PER_STEP = 2; };
-template <> struct WgradCfg<kFP32> { static constexpr int TILES_PER_STEP = 1; };
-
-template <int P>
-__global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradArgs a) {
-  using M = Mma<P>;
-  using Frag = typename M::Frag;
-  constexpr int TPS = WgradCfg<P>::TILES_PER_STEP;
-  constexpr int KS_H = Blob<P>::KS_H;
-  constexpr int TILE_BYTES_MAX = 2 * KS_H * 1024;
-  constexpr int SLOT = TPS * TILE_BYTES_MAX;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  int ji = 0;
-  while (ji + 1 < a.n_jobs && a.job[ji + 1].split_begin <= (int)blockIdx.x) ++ji;
-  const WgradJob& J = a.job[ji];
-  const int split = blockIdx.x - J.split_begin;
-  const int64_t n_steps = (a.n_tiles + TPS - 1) / TPS;
-  const int64_t s0 = n_steps * split / J.n_splits, s1 = n_steps * (split + 1) / J.n_splits;
-  const int tile_bytes = (J.a_ks + J.b_ks) * 1024;
-  const int pieces = TPS * (J.a_ks + J.b_ks);
-
-  auto issue = [&](int64_t step, int slot) {
-    char* dst = smem + slot * SLOT;
-    for (int p = wave; p < pieces; p += 4) {
-      const int t = p / (J.a_ks + J.b_ks), blk = p - t * (J.a_ks + J.b_ks);
-      int64_t tile = step * TPS + t;
-      if (tile >= a.n_tiles) tile = a.n_tiles - 1;  // tail: duplicated tile, masked out below
-      const char* src = blk < J.a_ks ? a.ws + J.a_off + (tile * J.a_ks + blk) * 1024
-                                     : a.act + J.b_off + (tile * J.b_ks + (blk - J.a_ks)) * 1024;
-      __builtin_amdgcn_global_load_lds(src + lane * 16, SNR_LDS(dst + p * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[2][8];
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < 8; ++y)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-  float bsum[2] = {0.f, 0.f};
-  const int ta0 = 2 * wave;
-
-  if (s0 < s1) issue(s0, 0);
-  int slot = 0;
-  for (int64_t step = s0; step < s1; ++step) {
-    __syncthreads();
-    if (step + 1 < s1) issue(step + 1, slot ^ 1);
-    const char* sbase = smem + slot * SLOT;
-#pragma unroll
-    for (int t = 0; t < TPS; ++t) {
-      if (step * TPS + t >= a.n_tiles) break;
-      const char* tb_ = sbase + t * tile_bytes;
-      if constexpr (P == kBF16) {
-        // lane -> (group G, i'): G>>1 = sample half g, G&1 = which 16-neuron block of the 32-row tile
-        const int G = lane >> 4, ip = lane & 15, gg = G >> 1, bh = G & 1, c = ip & 3, r = ip >> 2;
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        auto tr = [&](const char* p) {
-          return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
-        };
-        auto frag_at = [&](const char* sec, int ks, int tI, int half) {
-          int blk = 2 * tI + bh;
-          if (blk >= ks) blk = ks - 1;
-          // physical row of sample s in block blk is s ^ (4*(blk&1))  (act_row)
-          const int s_lo = (16 * half + 8 * gg + r) ^ ((blk & 1) << 2);
-          const int s_hi = (16 * half + 8 * gg + 4 + r) ^ ((blk & 1) << 2);
-          const bf16x4 lo = tr(sec + blk * 1024 + s_lo * 32 + c * 8);
-          const bf16x4 hi = tr(sec + blk * 1024 + s_hi * 32 + c * 8);
-          return Frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        };
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          Frag fa[2];
-#pragma unroll
-          for (int x = 0; x < 2; ++x) {
-            fa[x] = frag_at(tb_, J.a_ks, ta0 + x, half);
-            if (J.bias_off >= 0) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) bsum[x] += (float)fa[x][e];
-            }
-          }
-#pragma unroll
-          for (int y = 0; y < 8; ++y) {
-            if (y < J.ntb) {
-              const Frag fb = frag_at(tb_ + J.a_ks * 1024, J.b_ks, y, half);
-#pragma unroll
-              for (int x = 0; x < 2; ++x)
-                if (ta0 + x < J.nta) acc[x][y] = M::mma(fa[x], fb, acc[x][y]);
-            }
-          }
-        }
-      } else {
-        // fp32: A[i = neuron][k = sample 2*ks2 + g], one float per lane; saved layout [q = neuron/8][sample][8]
-        const int i = lane & 31, gg = lane >> 5;
-        const float* fa_base = (const float*)tb_;
-        const float* fb_base = (const float*)(tb_ + J.a_ks * 1024);
-        auto elem = [&](const float* sec, int ks, int tI, int s) {
-          int q = 4 * tI + (i >> 3);
-          if (q >= ks) q = ks - 1;
-          return sec[(q * 32 + s) * 8 + (i & 7)];
-        };
-#pragma unroll 4
-        for (int ks2 = 0; ks2 < 16; ++ks2) {
-          const int s = 2 * ks2 + gg;
-          float fa[2];
-#pragma unroll
-          for (int x = 0; x < 2; ++x) {
-            fa[x] = elem(fa_base, J.a_ks, ta0 + x, s);
-            if (J.bias_off >= 0) bsum[x] += fa[x];
-          }
-#pragma unroll
-          for (int y = 0; y < 8; ++y) {
-            if (y < J.ntb) {
-              const float fb = elem(fb_base, J.b_ks, y, s);
-#pragma unroll
-              for (int x = 0; x < 2; ++x)
-                if (ta0 + x < J.nta)
-                  acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x], fb, acc[x][y], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-    slot ^= 1;
-  }
-
-  // partials: [split][nta*32][ntb*32] row-major
-  const int NB = J.ntb * 32;
-  float* part = a.part + J.part_off + (int64_t)split * J.nta * 32 * NB;
-  const int jj = lane & 31, gq = lane >> 5;
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    if (ta0 + x >= J.nta) continue;
-#pragma unroll
-    for (int y = 0; y < 8; ++y) {
-      if (y >= J.ntb) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * (ta0 + x) + (r & 3) + 8 * (r >> 2) + 4 * gq;
-        part[(int64_t)row * NB + 32 * y + jj] = acc[x][y][r];
-      }
-    }
-    if (J.bias_off >= 0) {
-      float bs = bsum[x];
-      if constexpr (P == kBF16) {
-        // lanes l and l^32 hold the two sample halves of the same neuron
-        bs += __shfl_xor(bs, 32, 64);
-        if (lane < 32) {
-          // lane -> neuron row of the tile: group bh = (lane>>4)&1, ip = lane&15  => row = 16*bh + ip = lane
-          a.part[J.bias_part_off + (int64_t)split * J.nta * 32 + 32 * (ta0 + x) + lane] = bs;
-        }
-      } else {
-        bs += __shfl_xor(bs, 32, 64);
-        if (lane < 32) a.part[J.bias_part_off + (int64_t)split * J.nta * 32 + 32 * (ta0 + x) + lane] = bs;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// 3. reduce + scatter to the reference's parameter layout
-// ------------------------------------------------------------------------------------------
-template <int P> __device__ __forceinline__ int slot_true_index(int kind, int x, int L) {
-  constexpr int EPF = Prec<P>::EPF;
-  const int q = x / (2 * EPF), g = (x % (2 * EPF)) / EPF, e = x % EPF;
-  if (kind == SRC_H) return h_slot_neuron<P>(q, g, e);
-  if (kind == SRC_ENC_PTS || kind == SRC_ENC_DIR) return enc_slot_feature<P>(q, g, e, L);
-  return (P == kBF16) ? 8 * g + e : 2 * e + g;  // SRC_OUT (single frag): raw channel
-}
-
-template <int P>
-__global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad) {
-  // blockIdx.y = job; threads cover (row a, col b) plus one extra column (b == NB) for the bias
-  const WgradJob& J = a.job[blockIdx.y];
-  const int NA = J.nta * 32, NB = J.ntb * 32;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)NA * (NB + 1)) return;
-  const int ra = (int)(idx / (NB + 1)), cb = (int)(idx % (NB + 1));
-  if (ra >= J.a_ks * 2 * Prec<P>::EPF) return;
-  int n = slot_true_index<P>(J.a_kind, ra, 0) - (J.a_kind == SRC_OUT ? J.row_off : 0);
-  if (n < 0 || n >= J.rows_valid) return;
-  if (cb == NB) {
-    if (J.bias_off < 0) return;
-    float s = 0.f;
-    for (int sp = 0; sp < J.n_splits; ++sp) s += a.part[J.bias_part_off + (int64_t)sp * NA + ra];
-    grad[J.bias_off + n] += s;
-    return;
-  }
-  if (cb >= J.b_ks * 2 * Prec<P>::EPF) return;
-  const int k = slot_true_index<P>(J.b_kind, cb, J.b_kind == SRC_ENC_DIR ? a.L_dir : a.L_pts);
-  if (k < 0 || k >= J.cols_valid) return;
-  float s = 0.f;
-  const float* p = a.part + J.part_off + (int64_t)ra * NB + cb;
-  for (int sp = 0; sp < J.n_splits; ++sp) s += p[(int64_t)sp * NA * NB];
-  grad[J.w_off + (int64_t)n * J.ld + J.col_off + k] += s;
-}
-
-// ------------------------------------------------------------------------------------------
-// host: job list
-// ------------------------------------------------------------------------------------------
-template <int P>
-static WgradArgs make_jobs(const snr_mlp_config* c, int64_t n_samples, int64_t* part_floats, int* total_splits) {
-  using B = Blob<P>;
-  const int vd = c->use_viewdirs;
-  const ParamLayout L = make_param_layout(c->multires, c->multires_views, vd, c->out_ch, c->i_embed == -1);
-  const ActLayout<P> AL(n_samples, vd);
-  const WsLayout<P> WL(n_samples, vd);
-  WgradArgs A{};
-  A.n_tiles = AL.n_tiles;
-  A.L_pts = c->i_embed == -1 ? 0 : c->multires;
-  A.L_dir = c->i_embed == -1 ? 0 : c->multires_views;
-  int n = 0;
-  auto add = [&](int64_t a_off, int a_ks, int a_kind, int nta, int64_t b_off, int b_ks, int b_kind, int ntb,
-                 int64_t w_off, int ld, int col_off, int row_off, int rows_valid, int cols_valid, int64_t bias_off) {
-    WgradJob& J = A.job[n++];
-    J.a_off = a_off; J.a_ks = a_ks; J.a_kind = a_kind; J.nta = nta;
-    J.b_off = b_off; J.b_ks = b_ks; J.b_kind = b_kind; J.ntb = ntb;
-    J.w_off = (int)w_off; J.ld = ld; J.col_off = col_off; J.row_off = row_off; J.rows_valid = rows_valid;
-    J.cols_valid = cols_valid; J.bias_off = (int)bias_off;
-  };
-  const int ip = L.in_pts;
-  add(WL.off_dz(0), B::KS_H, SRC_H, 8, AL.off_pe(), B::KS_PE, SRC_ENC_PTS, 2, L.w_pts[0], ip, 0, 0, kW, ip, L.b_pts[0]);
-  for (int i = 1; i < 8; ++i) {
-    if (i == kSkip + 1) {
-      add(WL.off_dz(i), B::KS_H, SRC_H, 8, AL.off_pe(), B::KS_PE, SRC_ENC_PTS, 2, L.w_pts[i], kW + ip, 0, 0, kW, ip,
-          L.b_pts[i]);
-      add(WL.off_dz(i), B::KS_H, SRC_H, 8, AL.off_h(i - 1), B::KS_H, SRC_H, 8, L.w_pts[i], kW + ip, ip, 0, kW, kW, -1);
-    } else {
-      add(WL.off_dz(i), B::KS_H, SRC_H, 8, AL.off_h(i - 1), B::KS_H, SRC_H, 8, L.w_pts[i], kW, 0, 0, kW, kW, L.b_pts[i]);
-    }
-  }
-  if (vd) {
-    add(WL.off_dfeat(), B::KS_H, SRC_H, 8, AL.off_h(7), B::KS_H, SRC_H, 8, L.w_feat, kW, 0, 0, kW, kW, L.b_feat);
-    add(WL.off_dout(), 1, SRC_OUT, 1, AL.off_h(7), B::KS_H, SRC_H, 8, L.w_alpha, kW, 0, 3, 1, kW, L.b_alpha);
-    add(WL.off_dz9(), B::KS_H9, SRC_H, 4, AL.off_feat(), B::KS_H, SRC_H, 8, L.w_views, kW + L.in_dir, 0, 0, kW / 2, kW,
-        L.b_views);
-    if (L.in_dir > 0)
-      add(WL.off_dz9(), B::KS_H9, SRC_H, 4, AL.off_dir(), B::KS_DIR, SRC_ENC_DIR, 1, L.w_views, kW + L.in_dir, kW, 0,
-          kW / 2, L.in_dir, -1);
-    add(WL.off_dout(), 1, SRC_OUT, 1, AL.off_h9(), B::KS_H9, SRC_H, 4, L.w_rgb, kW / 2, 0, 0, 3, kW / 2, L.b_rgb);
-  } else {
-    add(WL.off_dout(), 1, SRC_OUT, 1, AL.off_h(7), B::KS_H, SRC_H, 8, L.w_out, kW, 0, 0, c->out_ch, kW, L.b_out);
-  }
-  A.n_jobs = n;
-  // split-K: the kernel is HBM-bound, so give each job workgroups in proportion to the bytes it streams
-  const int64_t n_steps = (A.n_tiles + WgradCfg<P>::TILES_PER_STEP - 1) / WgradCfg<P>::TILES_PER_STEP;
-  int64_t cost = 0;
-  for (int i = 0; i < n; ++i) cost += A.job[i].a_ks + A.job[i].b_ks;
-  const int target = 512;
-  int sb = 0;
-  int64_t po = 0;
-  for (int i = 0; i < n; ++i) {
-    WgradJob& J = A.job[i];
-    int64_t s = ((int64_t)target * (J.a_ks + J.b_ks) + cost / 2) / cost;
-    if (s < 1) s = 1;
-    if (s > n_steps) s = n_steps;
-    J.n_splits = (int)s; J.split_begin = sb; sb += (int)s;
-    J.part_off = po; po += s * J.nta * 32 * J.ntb * 32;
-    J.bias_part_off = po; po += s * J.nta * 32;
-  }
-  *part_floats = po;
-  *total_splits = sb;
-  return A;
+  pipe.drain();
 }
 
 }  // namespace snr
@@ -497,7 +183,7 @@ extern "C" int64_t snr_mlp_bwd_ws_bytes(const snr_mlp_config* c, int64_t n) {
 
 template <int P, bool VD>
 static int launch_dgrad(const DgradArgs& a, int64_t n_wg, hipStream_t s) {
-  const int lds = 2 * Pipe<P>::SLOT;
+  const int lds = kRingBytes;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_dgrad_kernel<P, VD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -505,7 +191,10 @@ static int launch_dgrad(const DgradArgs& a, int64_t n_wg, hipStream_t s) {
     attr_set = true;
   }
   const int64_t grid = n_wg < 1024 ? n_wg : 1024;
-  mlp_dgrad_kernel<P, VD><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+  {
+    ProfScope ps(K_MLP_DGRAD, s);
+    mlp_dgrad_kernel<P, VD><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+  }
   return launch_status();
 }
 
@@ -520,6 +209,7 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   }
   DgradArgs d{};
   d.blob_bwd = (const char*)packed + (int64_t)T.fwd_frags * 1024;
+  d.bwd_blocks = T.bwd_frags / kBlockFrags;
   d.d_raw = d_raw; d.n_samples = n; d.out_ch = c->out_ch;
   d.act = (const char*)act; d.ws = (char*)ws;
   const int64_t n_wg = (n + 127) / 128;
@@ -538,11 +228,17 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  mlp_wgrad_kernel<P><<<dim3((unsigned)total_splits), dim3(256), lds, s>>>(w);
+  {
+    ProfScope ps(K_MLP_WGRAD, s);
+    mlp_wgrad_kernel<P><<<dim3((unsigned)total_splits), dim3(256), lds, s>>>(w);
+  }
   st = launch_status();
   if (st != SNR_OK) return st;
   const int per_job = 256 * 257;
-  mlp_wgrad_reduce_kernel<P><<<dim3((per_job + 255) / 256, (unsigned)w.n_jobs), dim3(256), 0, s>>>(w, grad);
+  {
+    ProfScope ps(K_MLP_WGRAD_REDUCE, s);
+    mlp_wgrad_reduce_kernel<P><<<dim3((per_job + 255) / 256, (unsigned)w.n_jobs), dim3(256), 0, s>>>(w, grad);
+  }
   return launch_status();
 }
 

@@ -77,6 +77,7 @@ __global__ void mlp_pack_kernel(PackTable T, const float* __restrict__ params, c
 
 struct FwdArgs {
   const char* blob;        // packed weights (forward section first)
+  int fwd_blocks;          // 16 KiB blocks in the forward section (the cyclic DMA stream)
   const float* bias;       // bias block inside the blob
   int bias_floats;
   const float* pts;        // [n,3] or null
@@ -110,10 +111,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
   for (int i = tid; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
 
   Pipe<P> pipe;
-  pipe.slots = smem + kBiasLdsBytes;
-  pipe.gbase = pipe.gcur = a.blob;
-  pipe.slot = 0; pipe.wave = wave; pipe.lane = lane;
-  pipe.issue_into(0, KS_PE);  // chunk 0 of stage 0
+  pipe.init(smem + kBiasLdsBytes, a.blob, a.fwd_blocks, wave, lane);
+  __syncthreads();  // bias block visible to all waves
 
   const ActLayout<P> AL(a.n_samples, VD);
   const int64_t n_wg = AL.n_tiles / 4;
@@ -169,8 +168,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
         f32x16 acc = bias_tile(bias_lds, bias_off + 32 * nt, g);
-        if (nt == 0) acc = pipe.template step<KA, KB>(acc, sa, sb, KA + KB, false, pre);
-        else acc = pipe.template step<KA, KB>(acc, sa, sb, nt == 7 ? next_ks : KA + KB, false, nop);
+        if (nt == 0) acc = pipe.template step<KA, KB>(acc, sa, sb, 0, pre);
+        else acc = pipe.template step<KA, KB>(acc, sa, sb, nt * (KA + KB), nop);
         if (relu) {
           unsigned bits = 0;
 #pragma unroll
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
         if constexpr (TRAIN) { act_store(AL.off_h(7), KS_H, cur, KS_H); mask_store(AL.off_mask(7), mask7); }
       });
       f32x16 acc_a = bias_tile(bias_lds, kBiasAlphaTile, g);
-      acc_a = pipe.template step<0, KS_H>(acc_a, cur, cur, KS_H + KS_DIR, false, nop);
+      acc_a = pipe.template step<0, KS_H>(acc_a, cur, cur, 8 * KS_H, nop);
       const float alpha = acc_a[0];  // row 0 lives in register 0 of lanes 0..31
       // stage 9: views = relu(W [feat | dir] + b), 4 tiles -> h9 (in `cur` storage)
       Frag* feat = nxt;
@@ -237,10 +236,10 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
       for (int nt = 0; nt < 4; ++nt) {
         f32x16 acc = bias_tile(bias_lds, kBiasViews + 32 * nt, g);
         if (nt == 0)
-          acc = pipe.template step<KS_H, KS_DIR>(acc, feat, dir, KS_H + KS_DIR, false, [&]() {
+          acc = pipe.template step<KS_H, KS_DIR>(acc, feat, dir, 0, [&]() {
             if constexpr (TRAIN) act_store(AL.off_feat(), KS_H, feat, KS_H);
           });
-        else acc = pipe.template step<KS_H, KS_DIR>(acc, feat, dir, nt == 3 ? KS_H9 : KS_H + KS_DIR, false, nop);
+        else acc = pipe.template step<KS_H, KS_DIR>(acc, feat, dir, nt * (KS_H + KS_DIR), nop);
         unsigned bits = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -253,13 +252,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
       // stage 10: rgb
       f32x16 acc_c = bias_tile(bias_lds, kBiasRgb, g);
       const u32x4 mask9 = mask;
-      acc_c = pipe.template step<0, KS_H9>(acc_c, h9, h9, more ? KS_PE : 0, more, [&]() {
+      acc_c = pipe.template step<0, KS_H9>(acc_c, h9, h9, 0, [&]() {
         if constexpr (TRAIN) { act_store(AL.off_h9(), KS_H9, h9, KS_H9); mask_store(AL.off_mask9(), mask9); }
       });
       if (valid && g == 0) *(f32x4*)(a.raw + 4 * m) = f32x4{acc_c[0], acc_c[1], acc_c[2], alpha};
     } else {
       f32x16 acc_o = bias_tile(bias_lds, kBiasOut, g);
-      acc_o = pipe.template step<0, KS_H>(acc_o, cur, cur, more ? KS_PE : 0, more, [&]() {
+      acc_o = pipe.template step<0, KS_H>(acc_o, cur, cur, 0, [&]() {
         if constexpr (TRAIN) { act_store(AL.off_h(7), KS_H, cur, KS_H); mask_store(AL.off_mask(7), mask7); }
       });
       // rows 0..3 = registers 0..3 of lane half 0; row 4 = register 0 of lane half 1
@@ -270,6 +269,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
       }
     }
   }
+  pipe.drain();  // prefetched blocks still in flight must land before the LDS allocation is released
 }
 
 }  // namespace snr
@@ -321,10 +321,12 @@ extern "C" int snr_mlp_pack(const snr_mlp_config* c, const float* params, void* 
   if (c->precision == SNR_PREC_BF16) {
     const PackTable T = table_of<kBF16>(c);
     const int64_t threads = (int64_t)(T.fwd_frags + T.bwd_frags) * 64;
+    ProfScope ps(K_MLP_PACK, s);
     mlp_pack_kernel<kBF16><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s>>>(T, params, (char*)packed);
   } else {
     const PackTable T = table_of<kFP32>(c);
     const int64_t threads = (int64_t)(T.fwd_frags + T.bwd_frags) * 64;
+    ProfScope ps(K_MLP_PACK, s);
     mlp_pack_kernel<kFP32><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s>>>(T, params, (char*)packed);
   }
   return launch_status();
@@ -332,7 +334,7 @@ extern "C" int snr_mlp_pack(const snr_mlp_config* c, const float* params, void* 
 
 template <int P, bool VD, bool TRAIN>
 static int launch_fwd(const FwdArgs& a, int64_t n_wg, hipStream_t s) {
-  const int lds = kBiasLdsBytes + 2 * Pipe<P>::SLOT;
+  const int lds = kBiasLdsBytes + kRingBytes;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<P, VD, TRAIN>,
@@ -341,7 +343,10 @@ static int launch_fwd(const FwdArgs& a, int64_t n_wg, hipStream_t s) {
     attr_set = true;
   }
   const int64_t grid = n_wg < 1024 ? n_wg : 1024;  // persistent-lite: 4 waves/CU -> 256 resident, stride the rest
-  mlp_fwd_kernel<P, VD, TRAIN><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+  {
+    ProfScope ps(K_MLP_FWD, s);
+    mlp_fwd_kernel<P, VD, TRAIN><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+  }
   return launch_status();
 }
 
@@ -360,6 +365,7 @@ extern "C" int snr_mlp_forward(const snr_mlp_config* c, const void* packed, cons
   const PackTable T = bf ? table_of<kBF16>(c) : table_of<kFP32>(c);
   FwdArgs a{};
   a.blob = (const char*)packed;
+  a.fwd_blocks = T.fwd_frags / kBlockFrags;
   a.bias = (const float*)((const char*)packed + (int64_t)(T.fwd_frags + T.bwd_frags) * 1024);
   a.bias_floats = T.bias_floats;
   a.pts = pts; a.rays = rays; a.ray_ld = ray_ld; a.z_vals = z_vals; a.viewdirs = viewdirs; a.vd_ld = viewdirs_ld;

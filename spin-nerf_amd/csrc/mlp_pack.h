@@ -53,7 +53,9 @@ inline PackTable make_pack_table(int multires, int multires_views, int use_viewd
   T.multires = identity ? 0 : multires;
   T.multires_views = identity ? 0 : multires_views;
   int frag = 0, n = 0;
+  constexpr int BF = 16;  // kBlockFrags: every entry (= stage) starts on a DMA block boundary
   auto add = [&](int tiles, int transposed, int rows_valid, PackSrc a, PackSrc b) {
+    frag = (frag + BF - 1) / BF * BF;
     PackEntry& E = T.e[n++];
     E.frag_begin = frag; E.n_tiles = tiles; E.transposed = transposed; E.rows_valid = rows_valid;
     E.src[0] = a; E.src[1] = b;
@@ -76,6 +78,7 @@ inline PackTable make_pack_table(int multires, int multires_views, int use_viewd
   } else {
     add(1, 0, out_ch, PackSrc{SRC_H, B::KS_H, (int)L.w_out, kW, 0, 0, 0}, none);
   }
+  frag = (frag + BF - 1) / BF * BF;
   T.fwd_frags = frag;
   // ---------------- dgrad (rows = input neurons, slots = output neurons) ----------------
   if (use_viewdirs) {
@@ -95,6 +98,7 @@ inline PackTable make_pack_table(int multires, int multires_views, int use_viewd
     const int co = (i == kSkip + 1) ? ip : 0;
     add(8, 1, kW, PackSrc{SRC_H, B::KS_H, (int)L.w_pts[i], ld, co, kW, 0}, none);
   }
+  frag = (frag + BF - 1) / BF * BF;
   T.bwd_frags = frag - T.fwd_frags;
   T.n_entries = n;
   // ---------------- biases ----------------

@@ -1,0 +1,22 @@
+// Optional per-kernel timing with HIP events on the launch stream (diagnostics for bench.py's
+// roofline line; off by default, zero cost when off).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace snr {
+
+enum KernelId {
+  K_MLP_PACK = 0, K_MLP_FWD, K_MLP_DGRAD, K_MLP_WGRAD, K_MLP_WGRAD_REDUCE, K_SAMPLE_COARSE, K_COMPOSITE_FWD,
+  K_COMPOSITE_BWD, K_SAMPLE_FINE, K_MAKE_RAYS, K_ADAM, K_COUNT
+};
+
+void prof_begin(int id, hipStream_t s);
+void prof_end(hipStream_t s);
+
+struct ProfScope {
+  hipStream_t s;
+  ProfScope(int id, hipStream_t st) : s(st) { prof_begin(id, s); }
+  ~ProfScope() { prof_end(s); }
+};
+
+}  // namespace snr

@@ -409,8 +409,11 @@ extern "C" int snr_sample_coarse(const float* rays, int ld, int64_t n_rays, int 
   SNR_CHECK_ARG(rays && z_vals, SNR_ERR_NULL);
   SNR_CHECK_ARG(n_rays > 0 && N > 0 && ld >= 8, SNR_ERR_SHAPE);
   const int64_t n = n_rays * N;
-  sample_coarse_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-      rays, ld, n_rays, N, lindisp, t_rand, z_vals);
+  {
+    ProfScope ps(K_SAMPLE_COARSE, (hipStream_t)stream);
+    sample_coarse_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        rays, ld, n_rays, N, lindisp, t_rand, z_vals);
+  }
   return launch_status();
 }
 
@@ -421,9 +424,12 @@ extern "C" int snr_composite_forward(const float* raw, int C, const float* z, co
   SNR_CHECK_ARG(raw && z && rays && rgb_map && disp_map && acc_map && depth_map && weights, SNR_ERR_NULL);
   SNR_CHECK_ARG(n_rays > 0 && S > 0 && C >= 4 && ld >= 6, SNR_ERR_SHAPE);
   const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
-  composite_fwd_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(raw, C, z, rays, ld, noise, n_rays, S, white,
-                                                                          rgb_map, disp_map, acc_map, depth_map,
-                                                                          weights, alpha);
+  {
+    ProfScope ps(K_COMPOSITE_FWD, (hipStream_t)stream);
+    composite_fwd_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(raw, C, z, rays, ld, noise, n_rays, S, white,
+                                                                            rgb_map, disp_map, acc_map, depth_map,
+                                                                            weights, alpha);
+  }
   return launch_status();
 }
 
@@ -435,8 +441,11 @@ extern "C" int snr_composite_backward(const float* raw, int C, const float* z, c
   SNR_CHECK_ARG(raw && z && rays && d_raw, SNR_ERR_NULL);
   SNR_CHECK_ARG(n_rays > 0 && S > 0 && C >= 4 && ld >= 6, SNR_ERR_SHAPE);
   const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
-  composite_bwd_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(
-      raw, C, z, rays, ld, noise, n_rays, S, white, detach, g_rgb, g_disp, g_acc, g_depth, g_w, g_alpha, d_raw);
+  {
+    ProfScope ps(K_COMPOSITE_BWD, (hipStream_t)stream);
+    composite_bwd_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(
+        raw, C, z, rays, ld, noise, n_rays, S, white, detach, g_rgb, g_disp, g_acc, g_depth, g_w, g_alpha, d_raw);
+  }
   return launch_status();
 }
 
@@ -454,8 +463,11 @@ extern "C" int snr_sample_fine(const float* z_coarse, const float* weights, cons
     if (e != hipSuccess) return (int)e;
   }
   const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
-  sample_fine_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(z_coarse, weights, u, n_rays, Nc, Nf, npow2,
-                                                                          z_out, z_samples, z_std);
+  {
+    ProfScope ps(K_SAMPLE_FINE, (hipStream_t)stream);
+    sample_fine_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(z_coarse, weights, u, n_rays, Nc, Nf, npow2,
+                                                                            z_out, z_samples, z_std);
+  }
   return launch_status();
 }
 
@@ -467,8 +479,11 @@ extern "C" int snr_make_rays(int H, int W, float focal, const float* c2w_host, i
   Pose p;
   for (int i = 0; i < 12; ++i) p.m[i] = c2w_host[i];
   const int64_t n = (int64_t)h * w;
-  make_rays_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-      H, W, focal, p, i0, j0, h, w, ndc, near, far, use_viewdirs, rays, ld);
+  {
+    ProfScope ps(K_MAKE_RAYS, (hipStream_t)stream);
+    make_rays_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        H, W, focal, p, i0, j0, h, w, ndc, near, far, use_viewdirs, rays, ld);
+  }
   return launch_status();
 }
 
@@ -479,7 +494,10 @@ extern "C" int snr_adam_step(float* params, const float* grads, float* m, float*
   const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)step));
   const int64_t threads = (n + 3) / 4;
-  adam_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-      params, grads, m, v, n, lr, b1, b2, eps, bc1, bc2s, gscale);
+  {
+    ProfScope ps(K_ADAM, (hipStream_t)stream);
+    adam_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        params, grads, m, v, n, lr, b1, b2, eps, bc1, bc2s, gscale);
+  }
   return launch_status();
 }

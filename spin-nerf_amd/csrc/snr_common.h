@@ -5,6 +5,7 @@
 
 #include "../../include/spinnerf_hip.h"
 #include "mlp_layout.h"
+#include "prof.h"
 
 namespace snr {
 

@@ -146,6 +146,10 @@ class NeRF(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def mark_weights_changed(self):
+        """call after writing ``flat`` through a raw pointer (in-place torch ops are detected by version)"""
+        self._packed_key = None
+
     def set_precision(self, precision):
         self.precision = precision
         self.cfg.precision = _PREC[precision]

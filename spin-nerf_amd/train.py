@@ -1,0 +1,68 @@
+"""Training step of the render path: render() -> MSE losses -> backward -> (RCCL all-reduce) -> Adam.
+
+Mirrors what one optimisation step of the reference's train() does around the hot path
+(DS_NeRF/run_nerf.py:1455-1490 render + img2mse(rgb)+img2mse(rgb0); :1611-1612 backward + Adam;
+:1616-1622 exponential lr decay).  The data feed, LaMa/LPIPS terms and logging of train() are out
+of scope.
+
+Data parallelism (new capability): rays shard by rank, every rank holds a full
+replica of both MLPs (2 x 2.4 MB), and the only collective is one all-reduce of each net's flat fp32
+gradient buffer per step over RCCL ("nccl" backend); Adam then runs on the flat buffers with the
+1/world_size scale folded into the kernel.
+"""
+import torch
+
+from . import ops
+from .render import render
+
+
+def img2mse(x, y):
+    return torch.mean((x - y) ** 2)
+
+
+class RenderTrainer:
+    def __init__(self, render_kwargs_train, lrate=5e-4, lrate_decay=250, world_size=1, process_group=None):
+        self.kw = dict(render_kwargs_train)
+        self.nets = [n for n in (self.kw.get('network_fn'), self.kw.get('network_fine')) if n is not None]
+        self.lrate, self.lrate_decay = lrate, lrate_decay
+        self.world_size, self.pg = world_size, process_group
+        self.global_step = 0
+        self.m = [torch.zeros_like(n.flat.data) for n in self.nets]
+        self.v = [torch.zeros_like(n.flat.data) for n in self.nets]
+
+    def broadcast_parameters(self, src=0):
+        """identical replicas at start (rank `src`'s init wins)"""
+        if self.world_size > 1:
+            import torch.distributed as dist
+            for n in self.nets:
+                dist.broadcast(n.flat.data, src=src, group=self.pg)
+
+    def current_lr(self):
+        # run_nerf.py:1616-1620: lrate * 0.1 ** (global_step / (lrate_decay * 1000))
+        return self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 1000)))
+
+    def step(self, H, W, focal, batch_rays, target_s, chunk=1024 * 32, **extra):
+        """one optimisation step on this rank's ray shard; returns (loss, rgb) detached"""
+        for n in self.nets:
+            n.flat.grad = None
+        rgb, disp, acc, depth, extras = render(H, W, focal, chunk=chunk, rays=batch_rays, retraw=True,
+                                               **extra, **self.kw)
+        loss = img2mse(rgb, target_s)                         # run_nerf.py:1482
+        if 'rgb0' in extras:
+            loss = loss + img2mse(extras['rgb0'], target_s)   # run_nerf.py:1488-1490
+        loss.backward()
+        self.apply_gradients()
+        return loss.detach(), rgb.detach()
+
+    def apply_gradients(self):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            works = [dist.all_reduce(n.flat.grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                     for n in self.nets]
+            for w in works:
+                w.wait()
+        self.global_step += 1
+        lr = self.current_lr()
+        for n, m, v in zip(self.nets, self.m, self.v):
+            ops.adam_step_(n.flat.data, n.flat.grad, m, v, lr, self.global_step, grad_scale=1.0 / self.world_size)
+            n.mark_weights_changed()   # written through a raw pointer: re-pack before the next forward
