@@ -40,7 +40,7 @@ struct DgradArgs {
 };
 
 template <int P, bool VD>
-__global__ __launch_bounds__(256) void mlp_dgrad_kernel(DgradArgs a) {
+__global__ __launch_bounds__(64 * Prec<P>::WAVES) void mlp_dgrad_kernel(DgradArgs a) {
   using B = Blob<P>;
   using M = Mma<P>;
   using Frag = typename M::Frag;
@@ -58,21 +58,22 @@ __global__ __launch_bounds__(256) void mlp_dgrad_kernel(DgradArgs a) {
 
   const ActLayout<P> AL(a.n_samples, VD);
   const WsLayout<P> WL(a.n_samples, VD);
-  const int64_t n_wg = AL.n_tiles / 4;
+  const int64_t n_wg = AL.n_tiles / Prec<P>::WAVES;
   auto nop = []() {};
   const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
     const bool more = wg + gridDim.x < n_wg;
-    const int64_t tile = wg * 4 + wave;
+    const int64_t tile = wg * Prec<P>::WAVES + wave;
     const int64_t m = tile * 32 + j;
     const bool valid = m < a.n_samples;
 
-    auto ws_store = [&](int64_t sec_off, int ks, const Frag* src, int n) {
-      char* base = a.ws + sec_off + (tile * ks) * 1024 + g * 16;
+    // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section: tile nt's share of the deferred stores
+    auto ws_store = [&](int64_t sec_off, int n, const Frag* src, int nt, int NT) {
+      char* base = a.ws + sec_off + (tile * n) * 1024 + g * 16;
 #pragma unroll
       for (int f = 0; f < 64; ++f)
-        if (f < n) *(Frag*)(base + f * 1024 + act_row<P>(j, f) * 32) = src[f];
+        if (f >= n * nt / NT && f < n * (nt + 1) / NT) *(Frag*)(base + f * 1024 + act_row<P>(j, f) * 32) = src[f];
     };
     auto mask_load = [&](int64_t sec_off) {
       return *(const u32x4*)(a.act + sec_off + tile * 1024 + lane * 16);
@@ -96,19 +97,18 @@ __global__ __launch_bounds__(256) void mlp_dgrad_kernel(DgradArgs a) {
     auto stage = [&](auto KA_, auto KB_, auto NT_, const Frag* sa, const Frag* sb, Frag* dst, bool use_mask,
                      int next_ks, bool wrap_last, auto&& pre) {
       constexpr int KA = decltype(KA_)::value, KB = decltype(KB_)::value, NT = decltype(NT_)::value;
+      const u32x4 mk = mk_cur;
+      pipe.template run_tiles<KA, KB, NT>(
+          sa, sb, [&](int) { return zero16; },
+          [&](int nt, f32x16 acc) {
+            if (use_mask) {
+              const unsigned bits = mk[nt >> 1] >> (16 * (nt & 1));
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        f32x16 acc = zero16;
-        const bool last = nt == NT - 1;
-        if (nt == 0) acc = pipe.template step<KA, KB>(acc, sa, sb, 0, pre);
-        else acc = pipe.template step<KA, KB>(acc, sa, sb, nt * (KA + KB), nop);
-        if (use_mask) {
-          const unsigned bits = mk_cur[nt >> 1] >> (16 * (nt & 1));
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = ((bits >> r) & 1u) ? acc[r] : 0.f;
-        }
-        acc_to_frags<P>(acc, dst + nt * FPT);
-      }
+              for (int r = 0; r < 16; ++r) acc[r] = ((bits >> r) & 1u) ? acc[r] : 0.f;
+            }
+            acc_to_frags<P>(acc, dst + nt * FPT);
+          },
+          pre);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -121,33 +121,33 @@ __global__ __launch_bounds__(256) void mlp_dgrad_kernel(DgradArgs a) {
       mk_cur = mask_load(AL.off_mask9());
       mk_next = mask_load(AL.off_mask(7));
       // d z9 = relu'(h9) * (W_rgb^T d rgb)                 -> hB[0..KS_H9)
-      stage(I1{}, I0{}, I4{}, &dout, &dout, hB, true, KS_H9, false, [&]() { ws_store(WL.off_dout(), 1, &dout, 1); });
+      stage(I1{}, I0{}, I4{}, &dout, &dout, hB, true, KS_H9, false, [&](int nt) { ws_store(WL.off_dout(), 1, &dout, nt, 4); });
       // d feat = W_views[:, :256]^T d z9                    -> hA
-      stage(IH9{}, I0{}, I8{}, hB, hB, hA, false, KS_H + 1, false, [&]() { ws_store(WL.off_dz9(), KS_H9, hB, KS_H9); });
+      stage(IH9{}, I0{}, I8{}, hB, hB, hA, false, KS_H + 1, false, [&](int nt) { ws_store(WL.off_dz9(), KS_H9, hB, nt, 8); });
       // d z7 = relu'(h7) * (W_feat^T d feat + W_alpha^T d alpha) -> hB
       mk_cur = mk_next;
       mk_next = mask_load(AL.off_mask(6));
-      stage(IH{}, I1{}, I8{}, hA, &dout, hB, true, KS_H, false, [&]() { ws_store(WL.off_dfeat(), KS_H, hA, KS_H); });
+      stage(IH{}, I1{}, I8{}, hA, &dout, hB, true, KS_H, false, [&](int nt) { ws_store(WL.off_dfeat(), KS_H, hA, nt, 8); });
     } else {
       mk_cur = mask_load(AL.off_mask(7));
       mk_next = mask_load(AL.off_mask(6));
       // d z7 = relu'(h7) * (W_out^T d raw)                  -> hB
-      stage(I1{}, I0{}, I8{}, &dout, &dout, hB, true, KS_H, false, [&]() { ws_store(WL.off_dout(), 1, &dout, 1); });
+      stage(I1{}, I0{}, I8{}, &dout, &dout, hB, true, KS_H, false, [&](int nt) { ws_store(WL.off_dout(), 1, &dout, nt, 8); });
     }
     // d z_{i-1} = relu'(h_{i-1}) * (W_i^T d z_i), i = 7..1 ; d z7 is in hB
     for (int it = 0; it < 3; ++it) {
       const int i = 7 - 2 * it;  // consumes d z_i from hB
       mk_cur = mk_next;
       mk_next = mask_load(AL.off_mask(i - 2));
-      stage(IH{}, I0{}, I8{}, hB, hB, hA, true, KS_H, false, [&]() { ws_store(WL.off_dz(i), KS_H, hB, KS_H); });
+      stage(IH{}, I0{}, I8{}, hB, hB, hA, true, KS_H, false, [&](int nt) { ws_store(WL.off_dz(i), KS_H, hB, nt, 8); });
       mk_cur = mk_next;
       mk_next = mask_load(AL.off_mask(i - 3 >= 0 ? i - 3 : 0));
-      stage(IH{}, I0{}, I8{}, hA, hA, hB, true, KS_H, false, [&]() { ws_store(WL.off_dz(i - 1), KS_H, hA, KS_H); });
+      stage(IH{}, I0{}, I8{}, hA, hA, hB, true, KS_H, false, [&](int nt) { ws_store(WL.off_dz(i - 1), KS_H, hA, nt, 8); });
     }
     // i = 1: d z0 from d z1 (hB) -> hA; prefetch wraps to the first chunk for the next tile
     mk_cur = mk_next;
-    stage(IH{}, I0{}, I8{}, hB, hB, hA, true, more ? FIRST_KS : 0, more, [&]() { ws_store(WL.off_dz(1), KS_H, hB, KS_H); });
-    ws_store(WL.off_dz(0), KS_H, hA, KS_H);
+    stage(IH{}, I0{}, I8{}, hB, hB, hA, true, more ? FIRST_KS : 0, more, [&](int nt) { ws_store(WL.off_dz(1), KS_H, hB, nt, 8); });
+    ws_store(WL.off_dz(0), KS_H, hA, 0, 1);
   }
   pipe.drain();
 }
@@ -182,7 +182,8 @@ extern "C" int64_t snr_mlp_bwd_ws_bytes(const snr_mlp_config* c, int64_t n) {
 }
 
 template <int P, bool VD>
-static int launch_dgrad(const DgradArgs& a, int64_t n_wg, hipStream_t s) {
+static int launch_dgrad(const DgradArgs& a, hipStream_t s) {
+  const int64_t n_wg = padded_tiles<P>(a.n_samples) / Prec<P>::WAVES;
   const int lds = kRingBytes;
   static bool attr_set = false;
   if (!attr_set) {
@@ -193,7 +194,7 @@ static int launch_dgrad(const DgradArgs& a, int64_t n_wg, hipStream_t s) {
   const int64_t grid = n_wg < 1024 ? n_wg : 1024;
   {
     ProfScope ps(K_MLP_DGRAD, s);
-    mlp_dgrad_kernel<P, VD><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+    mlp_dgrad_kernel<P, VD><<<dim3((unsigned)grid), dim3(64 * Prec<P>::WAVES), lds, s>>>(a);
   }
   return launch_status();
 }
@@ -212,8 +213,7 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   d.bwd_blocks = T.bwd_frags / kBlockFrags;
   d.d_raw = d_raw; d.n_samples = n; d.out_ch = c->out_ch;
   d.act = (const char*)act; d.ws = (char*)ws;
-  const int64_t n_wg = (n + 127) / 128;
-  int st = c->use_viewdirs ? launch_dgrad<P, true>(d, n_wg, s) : launch_dgrad<P, false>(d, n_wg, s);
+  int st = c->use_viewdirs ? launch_dgrad<P, true>(d, s) : launch_dgrad<P, false>(d, s);
   if (st != SNR_OK) return st;
 
   int64_t pf; int total_splits;
@@ -221,7 +221,7 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   w.act = (const char*)act;
   w.ws = (const char*)ws;
   w.part = (float*)((char*)ws + WsLayout<P>(n, c->use_viewdirs).dz_bytes());
-  constexpr int lds = 2 * WgradCfg<P>::TILES_PER_STEP * 2 * Blob<P>::KS_H * 1024;
+  constexpr int lds = WgradCfg<P>::RING * 2 * Blob<P>::KS_H * 1024;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_wgrad_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -230,7 +230,7 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   }
   {
     ProfScope ps(K_MLP_WGRAD, s);
-    mlp_wgrad_kernel<P><<<dim3((unsigned)total_splits), dim3(256), lds, s>>>(w);
+    mlp_wgrad_kernel<P><<<dim3((unsigned)total_splits), dim3(64 * kWgradWaves), lds, s>>>(w);
   }
   st = launch_status();
   if (st != SNR_OK) return st;

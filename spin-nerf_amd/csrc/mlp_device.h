@@ -27,24 +27,28 @@ template <int P> __device__ __forceinline__ int act_row(int j, int f) {
 
 // Weight stream.  The packed weights of one pass over the network are a cyclic sequence of
 // 16 KiB blocks (kBlockFrags fragments of 1 KiB); every stage starts on a block boundary
-// (mlp_pack.h pads).  Blocks are DMA'd global->LDS (global_load_lds_dwordx4, 4 per wave per block)
+// (mlp_pack.h pads).  Blocks are DMA'd global->LDS (global_load_lds_dwordx4, 16/WAVES per wave per block)
 // into a ring of kRing slots, kDepth blocks ahead of the MFMAs that consume them.  Entering a new
 // block costs one counted wait + one raw s_barrier:
-//   s_waitcnt vmcnt(4*(kDepth-1))  this wave's pieces of the block have landed (DMA loads retire in
+//   s_waitcnt vmcnt(pieces*(kDepth-1))  this wave's pieces of the block have landed (DMA loads retire in
 //                                  order; stores sharing the counter can only make the wait stricter)
 //   s_barrier                      ... and so have everybody else's; everybody has at least started the
 //                                  previous block, so the slot of the one before it (cur-2) can be
 //                                  re-filled with block cur+kDepth while reads of cur-1 may still fly.
 // No __syncthreads(): its fence would drain the whole prefetch queue (vmcnt(0)) every time.
+#ifndef SNR_ABLATE
+#define SNR_ABLATE 0
+#endif
 constexpr int kBlockFrags = 16;
-constexpr int kRing = 8;
-constexpr int kDepth = 6;   // = kRing - 2: the slot re-filled on entering block b is that of block b-2
+constexpr int kRing = 6;
+constexpr int kDepth = 4;    // = kRing - 2: the slot re-filled on entering block b is that of block b-2
 constexpr int kRingBytes = kRing * kBlockFrags * 1024;
 
 template <int P> struct Pipe {
   using M = Mma<P>;
   using Frag = typename M::Frag;
   static constexpr int BF = kBlockFrags, BLOCK = kBlockFrags * 1024;
+  static constexpr int WAVES = Prec<P>::WAVES, PIECES = kBlockFrags / Prec<P>::WAVES;
   char* ring;
   const char* gbase;
   int n_blocks;      // blocks in the cyclic stream
@@ -63,15 +67,21 @@ template <int P> struct Pipe {
     const char* src = gbase + (int64_t)issue_blk * BLOCK + wave * 1024 + lane * 16;
     char* dst = ring + issue_slot * BLOCK + wave * 1024;
 #pragma unroll
-    for (int p = 0; p < BF / 4; ++p)
-      __builtin_amdgcn_global_load_lds(src + p * 4096, SNR_LDS(dst + p * 4096), 16, 0, 0);
+    for (int p = 0; p < PIECES; ++p)
+      __builtin_amdgcn_global_load_lds(src + p * WAVES * 1024, SNR_LDS(dst + p * WAVES * 1024), 16, 0, 0);
     issue_blk = issue_blk + 1 == n_blocks ? 0 : issue_blk + 1;
     issue_slot = issue_slot + 1 == kRing ? 0 : issue_slot + 1;
   }
 
   __device__ __forceinline__ void acquire() {
-    static_assert(kDepth == 6 && kBlockFrags == 16, "update the vmcnt immediate");
-    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // 4 * (kDepth - 1)
+#if SNR_ABLATE >= 1   // timing experiments only (results are garbage): no wait / barrier / DMA
+    cur_slot = cur_slot + 1 == kRing ? 0 : cur_slot + 1;
+    return;
+#endif
+    // allowed outstanding = this wave's pieces of the kDepth-1 younger blocks
+    static_assert(PIECES * (kDepth - 1) == 6 || PIECES * (kDepth - 1) == 12, "add the immediate");
+    if constexpr (PIECES * (kDepth - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     cur_slot = cur_slot + 1 == kRing ? 0 : cur_slot + 1;
@@ -80,28 +90,52 @@ template <int P> struct Pipe {
 
   __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-  // One output tile: KA + KB MFMA groups against the two register sources; `f0` is the position of
-  // the tile's first fragment inside its (block-aligned) stage, so block crossings are static.
-  // Weight fragments are read from LDS kAhead fragments ahead of the MFMA that consumes them.
-  // `pre` (deferred global stores) runs once, before the tile's first fragment.
-  template <int KA, int KB, class Pre>
-  __device__ __forceinline__ f32x16 step(f32x16 acc, const Frag* sa, const Frag* sb, int f0, Pre&& pre) {
-    constexpr int K = KA + KB;
+  // NT output tiles of one stage, each KA + KB MFMA groups against the two register sources.
+  //  * weight fragments come through a rolling window of G registers that runs ahead of the MFMAs
+  //    across tile boundaries (the stage starts block-aligned, so block crossings are static);
+  //  * init(nt) supplies the initial accumulator (bias), finish(nt, acc) the epilogue; the epilogue
+  //    of tile nt-1 is placed behind the first MFMA of tile nt so that its VALU work sits in the
+  //    shadow of that tile's dependent MFMA chain (one wave per SIMD: nothing else would hide it);
+  //  * pre(nt) issues tile nt's slice of the deferred global stores (the previous stage's output):
+  //    spread over the tiles so that no burst of stores sits in front of the counted DMA waits.
+  template <int KA, int KB, int NT, class Init, class Finish, class Pre>
+  __device__ __forceinline__ void run_tiles(const Frag* sa, const Frag* sb, Init&& init, Finish&& finish, Pre&& pre) {
+    constexpr int K = KA + KB, NF = NT * K;
     constexpr int G = (P == kBF16) ? 8 : 4;
-    Frag w[K];
-    auto load = [&](int f) {
-      if ((f0 + f) % BF == 0) acquire();
-      w[f] = *(const Frag*)(ring + cur_slot * BLOCK + ((f0 + f) % BF) * 1024 + lane * 16);
+    Frag w[G];
+    auto load = [&](int i) {
+      if (i % BF == 0) acquire();
+#if SNR_ABLATE >= 2   // no LDS reads either
+      asm volatile("" : "+v"(w[i % G]));
+#else
+      w[i % G] = *(const Frag*)(ring + cur_slot * BLOCK + (i % BF) * 1024 + lane * 16);
+#endif
     };
-    pre();
+#if SNR_ABLATE >= 2
 #pragma unroll
-    for (int f = 0; f < (G < K ? G : K); ++f) load(f);
+    for (int i = 0; i < G; ++i) w[i] = M::zero();
+#endif
 #pragma unroll
-    for (int f = 0; f < K; ++f) {
-      if (f + G < K) load(f + G);
-      acc = M::mma(w[f], f < KA ? sa[f < KA ? f : 0] : sb[f < KA ? 0 : f - KA], acc);
+    for (int i = 0; i < (G < NF ? G : NF); ++i) load(i);
+    f32x16 prev;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x16 acc = init(nt);
+#pragma unroll
+      for (int f = 0; f < K; ++f) {
+        const int i = nt * K + f;
+        acc = M::mma(w[i % G], f < KA ? sa[f < KA ? f : 0] : sb[f < KA ? 0 : f - KA], acc);
+        if (i + G < NF) load(i + G);
+        if (f == 0) {
+          pre(nt);   // this tile's slice of the deferred global stores
+#if SNR_ABLATE != 3
+          if (nt > 0) finish(nt - 1, prev);
+#endif
+        }
+      }
+      prev = acc;
     }
-    return acc;
+    finish(NT - 1, prev);
   }
 };
 
@@ -137,7 +171,16 @@ __device__ __forceinline__ void encode(float x, float y, float z, int L, int g, 
       if (p < 3 * L) {
         const int k = p / 3, ax = p - 3 * k;
         const float v = (ax == 0 ? x : (ax == 1 ? y : z)) * __builtin_ldexpf(1.0f, k);  // x * 2^k, exact
-        sincosf(v, &s, &c);
+        if constexpr (P == kBF16) {
+          // the result is rounded to bf16 (2^-9) right away: hardware sin/cos on the fractional number
+          // of revolutions (abs error ~1e-4 rad at |v| ~ 5000) instead of the ~80-instruction libm path
+          float rev = v * 0.15915494309189535f;
+          rev = rev - __builtin_floorf(rev);
+          s = __builtin_amdgcn_sinf(rev);
+          c = __builtin_amdgcn_cosf(rev);
+        } else {
+          sincosf(v, &s, &c);
+        }
       } else if (p == 3 * L) {
         s = x; c = y;
       } else if (p == 3 * L + 1) {

@@ -95,7 +95,7 @@ struct FwdArgs {
 };
 
 template <int P, bool VD, bool TRAIN>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
+__global__ __launch_bounds__(64 * Prec<P>::WAVES) void mlp_fwd_kernel(FwdArgs a) {
   using B = Blob<P>;
   using M = Mma<P>;
   using Frag = typename M::Frag;
@@ -108,19 +108,19 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, g = lane >> 5;
 
-  for (int i = tid; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
+  for (int i = tid; i < a.bias_floats; i += 64 * Prec<P>::WAVES) bias_lds[i] = a.bias[i];
 
   Pipe<P> pipe;
   pipe.init(smem + kBiasLdsBytes, a.blob, a.fwd_blocks, wave, lane);
   __syncthreads();  // bias block visible to all waves
 
   const ActLayout<P> AL(a.n_samples, VD);
-  const int64_t n_wg = AL.n_tiles / 4;
+  const int64_t n_wg = AL.n_tiles / Prec<P>::WAVES;
   auto nop = []() {};
 
   for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
     const bool more = wg + gridDim.x < n_wg;
-    const int64_t tile = wg * 4 + wave;
+    const int64_t tile = wg * Prec<P>::WAVES + wave;
     const int64_t m = tile * 32 + j;
     const bool valid = m < a.n_samples;
     const int64_t ray = valid ? m / a.S : 0;
@@ -150,37 +150,38 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
     }
 
     // per-lane byte offset inside a [tile][ks][32][32B] section
-    auto act_store = [&](int64_t sec_off, int ks, const Frag* src, int n) {
-      char* base = a.act + sec_off + (tile * ks) * 1024 + g * 16;
+    // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section: tile nt's share of the deferred stores
+    auto act_store = [&](int64_t sec_off, int n, const Frag* src, int nt, int NT) {
+      char* base = a.act + sec_off + (tile * n) * 1024 + g * 16;
 #pragma unroll
       for (int f = 0; f < 16 * 4; ++f)
-        if (f < n) *(Frag*)(base + f * 1024 + act_row<P>(j, f) * 32) = src[f];
+        if (f >= n * nt / NT && f < n * (nt + 1) / NT) *(Frag*)(base + f * 1024 + act_row<P>(j, f) * 32) = src[f];
     };
 
     Frag hA[KS_H], hB[KS_H];
     u32x4 mask = {0, 0, 0, 0};
 
-    // ---- generic 8-tile stage: dst = relu(W [sa|sb] + b) ----
+    // ---- generic stage: dst = [relu](W [sa|sb] + b), NT output tiles ----
+    auto relu_mask = [&](int nt, f32x16& acc) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        bits |= (acc[r] > 0.f ? 1u : 0u) << r;
+        acc[r] = fmaxf(acc[r], 0.f);
+      }
+      if constexpr (TRAIN) mask[nt >> 1] |= bits << (16 * (nt & 1));
+    };
     auto stage8 = [&](auto KA_, auto KB_, const Frag* sa, const Frag* sb, Frag* dst, int bias_off, int next_ks,
                       bool relu, auto&& pre) {
       constexpr int KA = decltype(KA_)::value, KB = decltype(KB_)::value;
       mask = u32x4{0, 0, 0, 0};
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        f32x16 acc = bias_tile(bias_lds, bias_off + 32 * nt, g);
-        if (nt == 0) acc = pipe.template step<KA, KB>(acc, sa, sb, 0, pre);
-        else acc = pipe.template step<KA, KB>(acc, sa, sb, nt * (KA + KB), nop);
-        if (relu) {
-          unsigned bits = 0;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            bits |= (acc[r] > 0.f ? 1u : 0u) << r;
-            acc[r] = fmaxf(acc[r], 0.f);
-          }
-          if constexpr (TRAIN) mask[nt >> 1] |= bits << (16 * (nt & 1));
-        }
-        acc_to_frags<P>(acc, dst + nt * FPT);
-      }
+      pipe.template run_tiles<KA, KB, 8>(
+          sa, sb, [&](int nt) { return bias_tile(bias_lds, bias_off + 32 * nt, g); },
+          [&](int nt, f32x16 acc) {
+            if (relu) relu_mask(nt, acc);
+            acc_to_frags<P>(acc, dst + nt * FPT);
+          },
+          pre);
     };
     using I0 = std::integral_constant<int, 0>;
     using IPE = std::integral_constant<int, KS_PE>;
@@ -192,19 +193,19 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
     };
 
     // stage 0: PE -> hA
-    stage8(IPE{}, I0{}, pe, pe, hA, bias_off_stage(0), KS_H, true, [&]() {
+    stage8(IPE{}, I0{}, pe, pe, hA, bias_off_stage(0), KS_H, true, [&](int nt) {
       if constexpr (TRAIN) {
-        act_store(AL.off_pe(), KS_PE, pe, KS_PE);
-        if constexpr (VD) act_store(AL.off_dir(), KS_DIR, dir, KS_DIR);
+        act_store(AL.off_pe(), KS_PE, pe, nt, 8);
+        if constexpr (VD) act_store(AL.off_dir(), KS_DIR, dir, nt, 8);
       }
     });
     // stages 1..7 ping-pong hA/hB; stage 5 prepends the encoding (skip connection, helpers:110-111)
     auto pre_of = [&](int s_prev, const Frag* src) {
       const u32x4 pmask = mask;
-      return [&, s_prev, src, pmask]() {
+      return [&, s_prev, src, pmask](int nt) {
         if constexpr (TRAIN) {
-          act_store(AL.off_h(s_prev), KS_H, src, KS_H);
-          mask_store(AL.off_mask(s_prev), pmask);
+          act_store(AL.off_h(s_prev), KS_H, src, nt, 8);
+          if (nt == 0) mask_store(AL.off_mask(s_prev), pmask);
         }
       };
     };
@@ -221,46 +222,49 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(FwdArgs a) {
     // cur = h7 (hB), nxt = hA
     const u32x4 mask7 = mask;
     if constexpr (VD) {
-      // stage 8: feature (8 tiles, no relu) + alpha tile
-      stage8(I0{}, IH{}, cur, cur, nxt, kBiasFeat, KS_H, false, [&]() {
-        if constexpr (TRAIN) { act_store(AL.off_h(7), KS_H, cur, KS_H); mask_store(AL.off_mask(7), mask7); }
-      });
-      f32x16 acc_a = bias_tile(bias_lds, kBiasAlphaTile, g);
-      acc_a = pipe.template step<0, KS_H>(acc_a, cur, cur, 8 * KS_H, nop);
-      const float alpha = acc_a[0];  // row 0 lives in register 0 of lanes 0..31
+      // stage 8: feature (8 tiles, no relu) + the alpha tile (row 0 = alpha_linear)
+      float alpha = 0.f;
+      pipe.template run_tiles<0, KS_H, 9>(
+          cur, cur, [&](int nt) { return bias_tile(bias_lds, kBiasFeat + 32 * nt, g); },
+          [&](int nt, f32x16 acc) {
+            if (nt < 8) acc_to_frags<P>(acc, nxt + nt * FPT);
+            else alpha = acc[0];  // row 0 lives in register 0 of lanes 0..31
+          },
+          [&](int nt) {
+            if constexpr (TRAIN) {
+              act_store(AL.off_h(7), KS_H, cur, nt, 9);
+              if (nt == 0) mask_store(AL.off_mask(7), mask7);
+            }
+          });
       // stage 9: views = relu(W [feat | dir] + b), 4 tiles -> h9 (in `cur` storage)
       Frag* feat = nxt;
       Frag* h9 = cur;
       mask = u32x4{0, 0, 0, 0};
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        f32x16 acc = bias_tile(bias_lds, kBiasViews + 32 * nt, g);
-        if (nt == 0)
-          acc = pipe.template step<KS_H, KS_DIR>(acc, feat, dir, 0, [&]() {
-            if constexpr (TRAIN) act_store(AL.off_feat(), KS_H, feat, KS_H);
+      pipe.template run_tiles<KS_H, KS_DIR, 4>(
+          feat, dir, [&](int nt) { return bias_tile(bias_lds, kBiasViews + 32 * nt, g); },
+          [&](int nt, f32x16 acc) {
+            relu_mask(nt, acc);
+            acc_to_frags<P>(acc, h9 + nt * FPT);
+          },
+          [&](int nt) {
+            if constexpr (TRAIN) act_store(AL.off_feat(), KS_H, feat, nt, 4);
           });
-        else acc = pipe.template step<KS_H, KS_DIR>(acc, feat, dir, nt * (KS_H + KS_DIR), nop);
-        unsigned bits = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          bits |= (acc[r] > 0.f ? 1u : 0u) << r;
-          acc[r] = fmaxf(acc[r], 0.f);
-        }
-        if constexpr (TRAIN) mask[nt >> 1] |= bits << (16 * (nt & 1));
-        acc_to_frags<P>(acc, h9 + nt * FPT);
-      }
       // stage 10: rgb
-      f32x16 acc_c = bias_tile(bias_lds, kBiasRgb, g);
       const u32x4 mask9 = mask;
-      acc_c = pipe.template step<0, KS_H9>(acc_c, h9, h9, 0, [&]() {
-        if constexpr (TRAIN) { act_store(AL.off_h9(), KS_H9, h9, KS_H9); mask_store(AL.off_mask9(), mask9); }
-      });
+      f32x16 acc_c;
+      pipe.template run_tiles<0, KS_H9, 1>(
+          h9, h9, [&](int) { return bias_tile(bias_lds, kBiasRgb, g); }, [&](int, f32x16 acc) { acc_c = acc; },
+          [&](int) {
+            if constexpr (TRAIN) { act_store(AL.off_h9(), KS_H9, h9, 0, 1); mask_store(AL.off_mask9(), mask9); }
+          });
       if (valid && g == 0) *(f32x4*)(a.raw + 4 * m) = f32x4{acc_c[0], acc_c[1], acc_c[2], alpha};
     } else {
-      f32x16 acc_o = bias_tile(bias_lds, kBiasOut, g);
-      acc_o = pipe.template step<0, KS_H>(acc_o, cur, cur, 0, [&]() {
-        if constexpr (TRAIN) { act_store(AL.off_h(7), KS_H, cur, KS_H); mask_store(AL.off_mask(7), mask7); }
-      });
+      f32x16 acc_o;
+      pipe.template run_tiles<0, KS_H, 1>(
+          cur, cur, [&](int) { return bias_tile(bias_lds, kBiasOut, g); }, [&](int, f32x16 acc) { acc_o = acc; },
+          [&](int) {
+            if constexpr (TRAIN) { act_store(AL.off_h(7), KS_H, cur, 0, 1); mask_store(AL.off_mask(7), mask7); }
+          });
       // rows 0..3 = registers 0..3 of lane half 0; row 4 = register 0 of lane half 1
       if (valid) {
         float* o = a.raw + (int64_t)a.out_ch * m;
@@ -333,7 +337,8 @@ extern "C" int snr_mlp_pack(const snr_mlp_config* c, const float* params, void* 
 }
 
 template <int P, bool VD, bool TRAIN>
-static int launch_fwd(const FwdArgs& a, int64_t n_wg, hipStream_t s) {
+static int launch_fwd(const FwdArgs& a, hipStream_t s) {
+  const int64_t n_wg = padded_tiles<P>(a.n_samples) / Prec<P>::WAVES;
   const int lds = kBiasLdsBytes + kRingBytes;
   static bool attr_set = false;
   if (!attr_set) {
@@ -342,10 +347,10 @@ static int launch_fwd(const FwdArgs& a, int64_t n_wg, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int64_t grid = n_wg < 1024 ? n_wg : 1024;  // persistent-lite: 4 waves/CU -> 256 resident, stride the rest
+  const int64_t grid = n_wg < 1024 ? n_wg : 1024;  // one workgroup per CU is resident; the rest grid-stride
   {
     ProfScope ps(K_MLP_FWD, s);
-    mlp_fwd_kernel<P, VD, TRAIN><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+    mlp_fwd_kernel<P, VD, TRAIN><<<dim3((unsigned)grid), dim3(64 * Prec<P>::WAVES), lds, s>>>(a);
   }
   return launch_status();
 }
@@ -372,12 +377,11 @@ extern "C" int snr_mlp_forward(const snr_mlp_config* c, const void* packed, cons
   a.n_samples = n_samples; a.S = samples_per_ray;
   a.multires = T.multires; a.multires_views = T.multires_views; a.out_ch = c->out_ch;
   a.raw = raw; a.act = (char*)act;
-  const int64_t n_wg = (n_samples + 127) / 128;
   hipStream_t s = (hipStream_t)stream;
   const bool vd = c->use_viewdirs, tr = act != nullptr;
 #define SNR_FWD(P_) \
-  (vd ? (tr ? launch_fwd<P_, true, true>(a, n_wg, s) : launch_fwd<P_, true, false>(a, n_wg, s)) \
-      : (tr ? launch_fwd<P_, false, true>(a, n_wg, s) : launch_fwd<P_, false, false>(a, n_wg, s)))
+  (vd ? (tr ? launch_fwd<P_, true, true>(a, s) : launch_fwd<P_, true, false>(a, s)) \
+      : (tr ? launch_fwd<P_, false, true>(a, s) : launch_fwd<P_, false, false>(a, s)))
   return bf ? SNR_FWD(kBF16) : SNR_FWD(kFP32);
 #undef SNR_FWD
 }

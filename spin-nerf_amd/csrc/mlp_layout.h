@@ -42,8 +42,15 @@ constexpr int kTileSamples = 32;
 enum Precision { kBF16 = 0, kFP32 = 1 };
 
 template <int P> struct Prec;
-template <> struct Prec<kBF16> { static constexpr int EPF = 8, FPT = 2, ESZ = 2; };
-template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4; };
+// WAVES = waves per workgroup of the chained kernels (forward, dgrad): one per SIMD, each with the
+// whole 512-entry VGPR+AGPR file (two 64-register activation sets + encodings + a rolling weight
+// window do not fit the 256 registers that two waves per SIMD would leave — measured: ~100 spills).
+template <> struct Prec<kBF16> { static constexpr int EPF = 8, FPT = 2, ESZ = 2, WAVES = 4; };
+template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4, WAVES = 4; };
+template <int P> SNR_HD int64_t padded_tiles(int64_t n_samples) {
+  constexpr int wg = kTileSamples * Prec<P>::WAVES;
+  return (n_samples + wg - 1) / wg * Prec<P>::WAVES;
+}
 
 // ---- k-slot -> neuron maps -------------------------------------------------------------
 

@@ -124,7 +124,7 @@ template <int P> struct ActLayout {
   using B = Blob<P>;
   int64_t n_tiles;
   int use_viewdirs;
-  SNR_HD ActLayout(int64_t n_samples, int vd) : n_tiles(((n_samples + 127) / 128) * 4), use_viewdirs(vd) {}
+  SNR_HD ActLayout(int64_t n_samples, int vd) : n_tiles(padded_tiles<P>(n_samples)), use_viewdirs(vd) {}
   // KiB per tile of each section
   SNR_HD int64_t kib_per_tile() const {
     return B::KS_PE + 8 * B::KS_H + 8 /*masks 0..7*/ + (use_viewdirs ? B::KS_DIR + B::KS_H + B::KS_H9 + 1 : 0);

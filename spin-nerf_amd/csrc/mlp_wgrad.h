@@ -1,6 +1,8 @@
 // Weight-gradient pass of the fused NeRF MLP backward (gfx950): split-K kernel + reduce/scatter.
 // Included by mlp_bwd.hip.  See the header comment there for the overall backward structure.
 #pragma once
+#include <stdlib.h>
+
 #include "snr_common.h"
 #include "mlp_pack.h"
 #include "mlp_device.h"
@@ -12,7 +14,7 @@ template <int P> struct WsLayout {
   using B = Blob<P>;
   int64_t n_tiles;
   int vd;
-  SNR_HD WsLayout(int64_t n_samples, int vd_) : n_tiles(((n_samples + 127) / 128) * 4), vd(vd_) {}
+  SNR_HD WsLayout(int64_t n_samples, int vd_) : n_tiles(padded_tiles<P>(n_samples)), vd(vd_) {}
   SNR_HD int64_t off_dout() const { return 0; }
   SNR_HD int64_t off_dz(int i) const { return n_tiles * 1024 * (1 + (int64_t)i * B::KS_H); }  // i in 0..7
   SNR_HD int64_t off_dfeat() const { return n_tiles * 1024 * (1 + 8 * (int64_t)B::KS_H); }
@@ -47,9 +49,11 @@ struct WgradArgs {
   int L_pts, L_dir;
 };
 
+// LDS ring of whole tiles (A section | B section of 32 samples).  bf16: 4 slots x 32 KiB, 3 tiles in
+// flight; fp32: 2 slots x 64 KiB, 1 in flight.
 template <int P> struct WgradCfg;
-template <> struct WgradCfg<kBF16> { static constexpr int TILES_PER_STEP = 2; };
-template <> struct WgradCfg<kFP32> { static constexpr int TILES_PER_STEP = 1; };
+template <> struct WgradCfg<kBF16> { static constexpr int RING = 4, DEPTH = 3; };
+template <> struct WgradCfg<kFP32> { static constexpr int RING = 2, DEPTH = 1; };
 
 // Everything a workgroup needs from its job, copied to registers once (the job table lives in the
 // kernarg segment; indexing it inside the hot loop costs a scalar load per use).
@@ -59,33 +63,58 @@ struct WgradLocal {
   float* part;
   float* bias_part;  // null = no bias
   int a_ks, b_ks, ntb_total;
-  int64_t s0, s1, n_tiles;
+  int64_t t0, t1;    // tile range of this split
 };
 
-// The whole life of one wave of a workgroup for a job whose output is NTB column tiles wide and
-// of which this wave owns NX (0..2) row tiles starting at ta0.  All waves (any NX) run the same
-// number of barriers and issue their share of the DMA.
-template <int P, int NTB, int NX>
-__device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int wave, int lane, int ta0) {
+// 8 waves per workgroup = two per SIMD: while one wave sits in the vector-memory issue queue (DMA)
+// or at a wait, its SIMD partner keeps the matrix pipe busy.  Each wave owns one 32-row tile of the
+// output (128 accumulator registers) across all column tiles.
+constexpr int kWgradWaves = 8;
+
+#if defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 2
+#define SNR_WGRAD_ISSUE(k) (void)0
+#else
+#define SNR_WGRAD_ISSUE(k) issue_piece(islot, (k))
+#endif
+
+// The whole life of one wave of a workgroup for a job whose output is NTB column tiles wide, of which
+// this wave owns NX (0..1) row tiles starting at ta0, and whose 32-sample tile is NI DMA
+// instructions per wave (short tiles re-load their last piece so every wave issues exactly NI: the
+// counted wait needs an immediate).  All waves (any NX) run the same barriers and DMA.
+// Everything that does not change from tile to tile (DMA source pointers, LDS offsets of the
+// transposing reads) is computed once up front; the per-tile loop is waits, 2*NI... DMA issues,
+// ds_read_b64_tr_b16 with immediate offsets, and MFMAs.
+template <int P, int NTB, int NX, int NI>
+__device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int wave, int lane, int ta0, int ni) {
   using M = Mma<P>;
   using Frag = typename M::Frag;
-  constexpr int TPS = WgradCfg<P>::TILES_PER_STEP;
-  constexpr int SLOT = TPS * 2 * Blob<P>::KS_H * 1024;
+  constexpr int R = WgradCfg<P>::RING, D = WgradCfg<P>::DEPTH;
+  constexpr int SLOT = 2 * Blob<P>::KS_H * 1024;
   const int a_ks = L.a_ks, b_ks = L.b_ks;
   const int per_tile = a_ks + b_ks;
-  const int tile_bytes = per_tile * 1024;
-  const int pieces = TPS * per_tile;
   const bool do_bias = L.bias_part != nullptr;
 
-  auto issue = [&](int64_t step, int slot) {
-    char* dst = smem + slot * SLOT;
-    for (int p = wave; p < pieces; p += 4) {
-      const int t = p >= per_tile ? 1 : 0;
-      const int blk = p - t * per_tile;
-      int64_t tile = step * TPS + t;
-      if (tile >= L.n_tiles) tile = L.n_tiles - 1;  // tail: duplicated tile, skipped by the compute loop
-      const char* src = blk < a_ks ? L.a_base + (tile * a_ks + blk) * 1024 : L.b_base + (tile * b_ks + (blk - a_ks)) * 1024;
-      __builtin_amdgcn_global_load_lds(src + lane * 16, SNR_LDS(dst + p * 1024), 16, 0, 0);
+  // ---- DMA pieces of this wave: wave + 8k (clamped), source pointer advances one tile per tile ----
+  const char* src[NI];
+  int lds_off[NI], stride[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    int p = wave + kWgradWaves * k;
+    if (p >= per_tile) p = per_tile - 1;
+    const bool isA = p < a_ks;
+    src[k] = (isA ? L.a_base + (L.t0 * a_ks + p) * 1024 : L.b_base + (L.t0 * b_ks + (p - a_ks)) * 1024) + lane * 16;
+    stride[k] = (isA ? a_ks : b_ks) * 1024;
+    lds_off[k] = p * 1024;
+  }
+  int64_t src_tile = L.t0;
+  auto issue_piece = [&](int slot, int k) {
+    if (k < ni) __builtin_amdgcn_global_load_lds(src[k], SNR_LDS(smem + slot * SLOT + lds_off[k]), 16, 0, 0);
+  };
+  auto advance = [&]() {   // past the end the last tile is re-loaded: the instruction count stays uniform
+    if (src_tile + 1 < L.t1) {
+      ++src_tile;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) src[k] += stride[k];
     }
   };
 
@@ -96,115 +125,132 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
     for (int y = 0; y < NTB; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-  float bsum[2] = {0.f, 0.f};
+  float bsum = 0.f;
 
-  // per-lane constants of the transposing read (bf16) / strided read (fp32)
+  // ---- tile-invariant LDS offsets of the reads ----
+  // bf16: 16-lane group G reads a [4 samples][16 neurons] block and receives its column `ip`;
+  // G>>1 = sample half gg (k-slots 8gg..8gg+7), G&1 = bh = which 16-neuron block of the 32-row tile;
+  // odd blocks store sample row r at r^4 (act_row).  Read q (0/1) fetches samples 8gg+4q..+3, so for
+  // block parity bh the physical row is 8gg + (4q ^ 4bh) + r4.  Offset within a tile section:
+  //   (2*tI + bh)*1024 + row*32 + c4*8 + half*512 ; everything but tI and half is per-lane constant.
   const int G = lane >> 4, ip = lane & 15, gg = G >> 1, bh = G & 1, c4 = ip & 3, r4 = ip >> 2;
+  const int bhA = a_ks == 1 ? 0 : bh;   // 16-wide OUT sections have one block: lanes of block 1 re-read block 0
+  int offA[2], offB[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    offA[q] = (2 * ta0 + bhA) * 1024 + (8 * gg + ((4 * q) ^ (4 * bhA)) + r4) * 32 + c4 * 8;
+    offB[q] = a_ks * 1024 + bh * 1024 + (8 * gg + ((4 * q) ^ (4 * bh)) + r4) * 32 + c4 * 8;
+  }
   const int i32 = lane & 31, g32 = lane >> 5;
 
-  if (L.s0 < L.s1) issue(L.s0, 0);
-  int slot = 0;
-  for (int64_t step = L.s0; step < L.s1; ++step) {
-    __syncthreads();
-    if (step + 1 < L.s1) issue(step + 1, slot ^ 1);
+#if !(defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 2)
+  for (int d = 0; d < D; ++d) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) issue_piece(d % R, k);
+    advance();
+  }
+#endif
+  int slot = 0, islot = D % R;
+  for (int64_t tile = L.t0; tile < L.t1; ++tile) {
+#if defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 2   // timing experiment: compute on whatever is in LDS
+    __builtin_amdgcn_s_barrier();
+#else
+    // this wave's pieces of `tile` have landed (DMA loads retire in order; nothing else is outstanding)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D == 1 ? 0 : NI * (D - 1)) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // ... and its reads of the previous tile are done
+    __builtin_amdgcn_s_barrier();                           // same for everybody: slot of tile-1 is free
+    asm volatile("" ::: "memory");
+#endif
+    int kq = 0;   // DMA pieces of tile + D issued so far
     if constexpr (NX > 0) {
-      const char* sbase = smem + slot * SLOT;
-#pragma unroll 1
-      for (int t = 0; t < TPS; ++t) {
-        if (step * TPS + t >= L.n_tiles) break;
-        const char* secA = sbase + t * tile_bytes;
-        const char* secB = secA + a_ks * 1024;
-        if constexpr (P == kBF16) {
-          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-          // 16-lane group G reads a [4 samples][16 neurons] block and receives its column `ip`:
-          // G>>1 = sample half (k-slots 8g..8g+7), G&1 = which 16-neuron block of the 32-row tile.
-          auto frag_at = [&](const char* sec, int ks, int tI, int half) {
-            int blk = 2 * tI + bh;
-            if (blk >= ks) blk = ks - 1;
-            const int sw = (blk & 1) << 2;   // act_row swizzle of odd blocks
-            const char* base = sec + blk * 1024 + c4 * 8;
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (__attribute__((address_space(3))) bf16x4*)(base + ((16 * half + 8 * gg + r4) ^ sw) * 32));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (__attribute__((address_space(3))) bf16x4*)(base + ((16 * half + 8 * gg + 4 + r4) ^ sw) * 32));
-            return Frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          };
-#pragma unroll 1
-          for (int half = 0; half < 2; ++half) {
-            Frag fa[NX];
+      char* sbase = smem + slot * SLOT;
+      if constexpr (P == kBF16) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) bf16x4* lds_b4;
+        char* pa0 = sbase + offA[0];
+        char* pa1 = sbase + offA[1];
+        char* pb0 = sbase + offB[0];
+        char* pb1 = sbase + offB[1];
 #pragma unroll
-            for (int x = 0; x < NX; ++x) {
-              fa[x] = frag_at(secA, a_ks, ta0 + x, half);
-              if (do_bias) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bsum[x] += (float)fa[x][e];
-              }
-            }
-#pragma unroll
-            for (int y = 0; y < NTB; ++y) {
-              const Frag fb = frag_at(secB, b_ks, y, half);
-#pragma unroll
-              for (int x = 0; x < NX; ++x) acc[x][y] = M::mma(fa[x], fb, acc[x][y]);
-            }
+        for (int half = 0; half < 2; ++half) {
+          Frag fa, fb[NTB];
+          {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pa0 + half * 512));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pa1 + half * 512));
+            fa = Frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           }
-        } else {
-          // fp32: A[i = neuron][k = sample 2*ks2 + g], one float per lane; saved layout [q = neuron/8][sample][8]
-          const float* fa_base = (const float*)secA;
-          const float* fb_base = (const float*)secB;
-          auto elem = [&](const float* sec, int ks, int tI, int s) {
-            int q = 4 * tI + (i32 >> 3);
-            if (q >= ks) q = ks - 1;
-            return sec[(q * 32 + s) * 8 + (i32 & 7)];
-          };
+#pragma unroll
+          for (int y = 0; y < NTB; ++y) {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pb0 + y * 2048 + half * 512));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pb1 + y * 2048 + half * 512));
+            fb[y] = Frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+          if (do_bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum += (float)fa[e];
+          }
+#pragma unroll
+          for (int y = 0; y < NTB; ++y) {
+            acc[0][y] = M::mma(fa, fb[y], acc[0][y]);
+            if ((NTB < 8 || (y & 1)) && kq < NI) { SNR_WGRAD_ISSUE(kq); ++kq; }
+          }
+        }
+      } else {
+        // fp32: A[i = neuron][k = sample 2*ks2 + g], one float per lane; saved layout [q = neuron/8][sample][8]
+        const float* fa_base = (const float*)sbase;
+        const float* fb_base = (const float*)(sbase + a_ks * 1024);
+        auto elem = [&](const float* sec, int ks, int tI, int sidx) {
+          int q = 4 * tI + (i32 >> 3);
+          if (q >= ks) q = ks - 1;
+          return sec[(q * 32 + sidx) * 8 + (i32 & 7)];
+        };
 #pragma unroll 4
-          for (int ks2 = 0; ks2 < 16; ++ks2) {
-            const int s = 2 * ks2 + g32;
-            float fa[NX];
+        for (int ks2 = 0; ks2 < 16; ++ks2) {
+          const int sidx = 2 * ks2 + g32;
+          const float fa = elem(fa_base, a_ks, ta0, sidx);
+          if (do_bias) bsum += fa;
 #pragma unroll
-            for (int x = 0; x < NX; ++x) {
-              fa[x] = elem(fa_base, a_ks, ta0 + x, s);
-              if (do_bias) bsum[x] += fa[x];
-            }
-#pragma unroll
-            for (int y = 0; y < NTB; ++y) {
-              const float fb = elem(fb_base, b_ks, y, s);
-#pragma unroll
-              for (int x = 0; x < NX; ++x)
-                acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x], fb, acc[x][y], 0, 0, 0);
-            }
+          for (int y = 0; y < NTB; ++y) {
+            const float fb = elem(fb_base, b_ks, y, sidx);
+            acc[0][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[0][y], 0, 0, 0);
           }
+          if (kq < NI) { SNR_WGRAD_ISSUE(kq); ++kq; }
         }
       }
     }
-    slot ^= 1;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (k >= kq) { SNR_WGRAD_ISSUE(k); }
+#if !(defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 2)
+    advance();
+#endif
+    islot = islot + 1 == R ? 0 : islot + 1;
+    slot = slot + 1 == R ? 0 : slot + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing re-loads
 
   if constexpr (NX > 0) {
     // partials: [nta*32][ntb*32] row-major for this split
     const int NB = L.ntb_total * 32;
 #pragma unroll
-    for (int x = 0; x < NX; ++x) {
+    for (int y = 0; y < NTB; ++y) {
 #pragma unroll
-      for (int y = 0; y < NTB; ++y) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 32 * (ta0 + x) + (r & 3) + 8 * (r >> 2) + 4 * g32;
-          L.part[(int64_t)row * NB + 32 * y + i32] = acc[x][y][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * ta0 + (r & 3) + 8 * (r >> 2) + 4 * g32;
+        L.part[(int64_t)row * NB + 32 * y + i32] = acc[0][y][r];
       }
-      if (do_bias) {
-        // lanes l and l^32 hold the two sample halves of the same neuron row (row = lane & 31)
-        const float bs = bsum[x] + __shfl_xor(bsum[x], 32, 64);
-        if (lane < 32) L.bias_part[32 * (ta0 + x) + lane] = bs;
-      }
+    }
+    if (do_bias) {
+      // lanes l and l^32 hold the two sample halves of the same neuron row (row = lane & 31)
+      const float bs = bsum + __shfl_xor(bsum, 32, 64);
+      if (lane < 32) L.bias_part[32 * ta0 + lane] = bs;
     }
   }
 }
 
 template <int P>
-__global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(64 * kWgradWaves) void mlp_wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TPS = WgradCfg<P>::TILES_PER_STEP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -212,31 +258,44 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradArgs a) {
   while (ji + 1 < a.n_jobs && a.job[ji + 1].split_begin <= (int)blockIdx.x) ++ji;
   const WgradJob& J = a.job[ji];
   const int split = blockIdx.x - J.split_begin;
-  const int64_t n_steps = (a.n_tiles + TPS - 1) / TPS;
   WgradLocal L;
   L.a_base = a.ws + J.a_off;
   L.b_base = a.act + J.b_off;
   L.a_ks = J.a_ks; L.b_ks = J.b_ks; L.ntb_total = J.ntb;
-  L.n_tiles = a.n_tiles;
-  L.s0 = n_steps * split / J.n_splits;
-  L.s1 = n_steps * (split + 1) / J.n_splits;
+  L.t0 = a.n_tiles * split / J.n_splits;
+  L.t1 = a.n_tiles * (split + 1) / J.n_splits;
   const int nta = J.nta, ntb = J.ntb;
   L.part = a.part + J.part_off + (int64_t)split * nta * 32 * ntb * 32;
   L.bias_part = J.bias_off >= 0 ? a.part + J.bias_part_off + (int64_t)split * nta * 32 : nullptr;
-  const int ta0 = 2 * wave;
-  const int nx = nta - ta0 >= 2 ? 2 : (nta - ta0 == 1 ? 1 : 0);
+  const int ta0 = wave;
+#if defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 1   // timing experiment: DMA stream only
+  const int nx = 0;
+#else
+  const int nx = ta0 < nta ? 1 : 0;
+#endif
 
-  // shapes that occur: 8x8 (256x256), 8x2 (x encodings), 4x8 / 4x1 (views layer), 1x8 / 1x4 (heads)
-  if (nx == 2) {
-    if (ntb == 8) wgrad_run<P, 8, 2>(L, smem, wave, lane, ta0);
-    else if (ntb == 2) wgrad_run<P, 2, 2>(L, smem, wave, lane, ta0);
-    else wgrad_run<P, 1, 2>(L, smem, wave, lane, ta0);
-  } else if (nx == 1) {
-    if (ntb == 8) wgrad_run<P, 8, 1>(L, smem, wave, lane, ta0);
-    else wgrad_run<P, 4, 1>(L, smem, wave, lane, ta0);
+  // shapes that occur (rows x cols in 32-tiles): 8x8 (256x256), 8x2 (x encodings), 4x8 / 4x1 (views
+  // layer), 1x8 / 1x4 (heads); ni = DMA instructions per wave per tile
+  const int ni = (J.a_ks + J.b_ks + kWgradWaves - 1) / kWgradWaves;
+#define SNR_RUN(NTB_, NX_, NI_) wgrad_run<P, NTB_, NX_, NI_>(L, smem, wave, lane, ta0, ni)
+  if constexpr (P == kFP32) {   // one tile in flight: the wait immediate is 0 whatever ni is
+    if (nx == 0) SNR_RUN(1, 0, 8);
+    else if (ntb == 8) SNR_RUN(8, 1, 8);
+    else if (ntb == 4) SNR_RUN(4, 1, 8);
+    else if (ntb == 2) SNR_RUN(2, 1, 8);
+    else SNR_RUN(1, 1, 8);
+  } else if (ni == 4) {
+    if (nx == 0) SNR_RUN(1, 0, 4); else SNR_RUN(8, 1, 4);
+  } else if (ni == 3) {
+    if (nx == 0) SNR_RUN(1, 0, 3);
+    else if (ntb == 8) SNR_RUN(8, 1, 3);
+    else SNR_RUN(2, 1, 3);
   } else {
-    wgrad_run<P, 1, 0>(L, smem, wave, lane, ta0);
+    if (nx == 0) SNR_RUN(1, 0, 2);
+    else if (ntb == 4) SNR_RUN(4, 1, 2);
+    else SNR_RUN(1, 1, 2);
   }
+#undef SNR_RUN
 }
 
 // ------------------------------------------------------------------------------------------
@@ -326,10 +385,13 @@ static WgradArgs make_jobs(const snr_mlp_config* c, int64_t n_samples, int64_t* 
   A.n_jobs = n;
   // split-K: the kernel streams saved activations once, so give each job workgroups in proportion
   // to the bytes it streams; ~2 workgroups per CU in total
-  const int64_t n_steps = (A.n_tiles + WgradCfg<P>::TILES_PER_STEP - 1) / WgradCfg<P>::TILES_PER_STEP;
+  const int64_t n_steps = A.n_tiles;
   int64_t cost = 0;
   for (int i = 0; i < n; ++i) cost += A.job[i].a_ks + A.job[i].b_ks;
-  const int target = 512;
+  // total workgroups: more than one per CU so that the dispatcher evens out the jobs' different
+  // cost per byte (tunable for experiments through SNR_WGRAD_SPLITS)
+  int target = 512;
+  if (const char* e = getenv("SNR_WGRAD_SPLITS")) target = atoi(e) > 0 ? atoi(e) : target;
   int sb = 0;
   int64_t po = 0;
   for (int i = 0; i < n; ++i) {
