@@ -61,7 +61,10 @@ def cpu_baseline(ns, H, W, focal, near, far):
     """The oracle's training step (oracle/nerf_oracle.py, a port of the reference's torch ops) on the
     host cores — a reported baseline, measured on a bounded sample of the same workload."""
     from oracle import nerf_oracle as O
-    torch.set_num_threads(os.cpu_count())
+    # measured on the MI355X host (256 hardware threads): torch's intra-op pool peaks at 32 threads for
+    # these shapes (8: 267, 16: 273, 32: 301, 64: 177, 128: 86 rays/s) — use the best, not the most
+    threads = min(os.cpu_count(), 32)
+    torch.set_num_threads(threads)
     n_rand = ns.n_rand
     sd_c = O.init_nerf_params(seed=0)
     sd_f = O.init_nerf_params(seed=1) if ns.n_fine > 0 else None
@@ -85,9 +88,9 @@ def cpu_baseline(ns, H, W, focal, near, far):
         O.train_step(sd_c, sd_f, opt, rays, target, kw, randoms=rnd)
         times.append(time.perf_counter() - t0)
     t = float(np.mean(times[1:]))
-    return {"value": n_rand / t, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": n_rand / t, "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{ns.cpu_steps} steps of {n_rand} rays x ({ns.n_coarse}+{ns.n_fine}) samples after 1 warm-up, "
-                      f"fp32 torch CPU ops, {os.cpu_count()} threads, anomaly detection off"}
+                      f"fp32 torch CPU ops, {threads} threads of a {os.cpu_count()}-thread host, anomaly detection off"}
 
 
 def main():
@@ -200,10 +203,16 @@ def main():
     dom = max((k for k in kernels if k in flops), key=lambda k: kernels[k]["ms_per_step"])
     peak = PEAK_TFLOPS[ns.precision]
     launches = kernels[dom]["launches_per_step"]
+    # HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r01_summary.md:
+    # 2 x FETCH_SIZE + WRITE_SIZE KiB, gfx950 correction per MI355X_MICROARCH.md); valid for the default workload
+    traffic = None
+    default_cfg = (ns.precision == "bf16" and ns.n_rand == 1024 and ns.n_coarse == 64 and ns.n_fine == 128)
+    if default_cfg and dom == "mlp_wgrad":
+        traffic = (2 * 7.28e5 + 1.04e5) * 1024
     roofline = {
         "kernel": dom, "bound": "mfma",
         "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kernels[dom]["tflops"] / peak,
-        "traffic": None,
+        "traffic": traffic,
         "flops_per_launch": flops[dom] * evals_per_step / launches,
         "avg_launch_ms": kernels[dom]["ms_per_step"] / launches,
     }

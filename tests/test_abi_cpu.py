@@ -1,0 +1,115 @@
+"""CPU: the C-ABI shared library loads without a GPU and exports every symbol that
+include/spinnerf_hip.h declares; size queries and argument validation work host-side; the Python
+host fails loudly (no fallback) when asked to compute without a device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def S():
+    import __graft_entry__ as g
+    import spin_nerf_amd as S
+    if not os.path.exists(S.LIB_PATH):
+        g.build()
+    return S
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "spinnerf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(snr_[a-z0-9_]+)\s*\(", src)) - {"snr_mlp_config"})
+
+
+def test_library_exports_every_declared_symbol(S):
+    lib = ctypes.CDLL(S.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/spinnerf_hip.h but not exported"
+    # and the ctypes table binds exactly the declared set
+    assert sorted(S._lib.SIGNATURES) == names
+
+
+def test_size_queries_and_validation_run_on_host(S):
+    lib = S._lib.load()
+    assert lib.snr_abi_version() == 1
+    cfg = S._lib.MlpConfig(10, 4, 0, 1, 4, S._lib.PREC_BF16)
+    assert lib.snr_mlp_param_count(cfg) == 595844          # SURVEY.md §8 a6 [measured]
+    assert lib.snr_mlp_packed_bytes(cfg) > 2 * 595844 * 2  # forward + transposed copies, bf16
+    n = 1024 * 192
+    assert lib.snr_mlp_act_bytes(cfg, n) > 0 and lib.snr_mlp_bwd_ws_bytes(cfg, n) > 0
+    assert lib.snr_mlp_act_bytes(cfg, 0) == -2             # SNR_ERR_SHAPE
+    bad = S._lib.MlpConfig(11, 4, 0, 1, 4, 0)
+    assert lib.snr_mlp_param_count(bad) == -3              # SNR_ERR_UNSUPPORTED
+    assert lib.snr_mlp_pack(cfg, None, None, None) == -1   # SNR_ERR_NULL
+    assert lib.snr_sample_coarse(None, 11, 4, 64, 0, None, None, None) == -1
+    assert b"NULL" in lib.snr_status_string(-1)
+
+
+def test_module_matches_reference_layout(S):
+    """state-dict keys/shapes of the reference NeRF (helpers:86-102); 595 844 parameters."""
+    torch.manual_seed(0)
+    m = S.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True)
+    sd = m.state_dict()
+    assert list(sd)[:4] == ["pts_linears.0.weight", "pts_linears.0.bias", "pts_linears.1.weight", "pts_linears.1.bias"]
+    assert sd["pts_linears.5.weight"].shape == (256, 319) and sd["views_linears.0.weight"].shape == (128, 283)
+    assert sd["alpha_linear.weight"].shape == (1, 256) and sd["rgb_linear.weight"].shape == (3, 128)
+    assert sum(v.numel() for v in sd.values()) == 595844 == m.flat.numel()
+    # same seed -> same init as a chain of nn.Linear built in the reference's order
+    torch.manual_seed(0)
+    first = torch.nn.Linear(63, 256)
+    assert torch.equal(sd["pts_linears.0.weight"], first.weight)
+    # round trip + strictness
+    m2 = S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True)
+    m2.load_state_dict(sd)
+    assert torch.equal(m2.flat, m.flat)
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict({k: v for k, v in sd.items() if k != "rgb_linear.bias"})
+    with pytest.raises(NotImplementedError):
+        S.NeRF(D=4, W=128, input_ch=63)
+
+
+def test_no_cpu_fallback(S):
+    """the product path refuses host tensors instead of computing on the CPU"""
+    m = S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True)
+    with pytest.raises(S.HipLibraryError):
+        m.query(torch.zeros(2, 4, 3), torch.zeros(2, 3))
+    with pytest.raises(S.HipLibraryError):
+        S.sample_coarse(torch.zeros(4, 11), 8)
+
+
+def test_missing_library_fails_loudly(S, monkeypatch):
+    monkeypatch.setattr(S._lib, "_lib", None)
+    monkeypatch.setattr(S._lib, "LIB_PATH", "/nonexistent/libspinnerf_hip.so")
+    with pytest.raises(S.HipLibraryError, match="missing"):
+        S._lib.load()
+
+
+def test_embedder_and_create_nerf_contract(S, tmp_path):
+    import argparse
+    e, d = S.get_embedder(10, 0)
+    assert d == 63 and S.get_embedder(4, 0)[1] == 27 and S.get_embedder(10, -1)[1] == 3
+    args = argparse.Namespace(multires=10, multires_views=4, i_embed=0, use_viewdirs=True, N_importance=128,
+                              N_samples=64, alpha_model_path=None, netdepth=8, netwidth=256, netdepth_fine=8,
+                              netwidth_fine=256, netchunk=65536, lrate=5e-4, basedir=str(tmp_path), expname="",
+                              ft_path=None, no_reload=True, perturb=1.0, white_bkgd=True, raw_noise_std=1.0,
+                              dataset_type="llff", no_ndc=True, lindisp=True, sigma_loss=False, no_coarse=False)
+    kw_train, kw_test, start, grad_vars, opt = S.create_nerf(args, device=torch.device("cpu"))
+    # run_nerf.py:465-492
+    assert set(kw_train) == {"network_query_fn", "perturb", "N_importance", "network_fine", "N_samples", "network_fn",
+                             "use_viewdirs", "white_bkgd", "raw_noise_std", "ndc", "lindisp"}
+    assert kw_train["ndc"] is False and kw_test["perturb"] is False and kw_test["raw_noise_std"] == 0.
+    assert start == 0 and len(grad_vars) == 2 and isinstance(opt, torch.optim.Adam)
+    # checkpoint interchange (run_nerf.py:1626-1636): a per-layer state dict loads into the flat module
+    ck = {"global_step": 7, "network_fn_state_dict": kw_train["network_fn"].state_dict(),
+          "network_fine_state_dict": kw_train["network_fine"].state_dict(), "optimizer_state_dict": opt.state_dict()}
+    torch.save(ck, tmp_path / "000007.tar")
+    args.no_reload = False
+    _, _, start2, _, _ = S.create_nerf(args, device=torch.device("cpu"))
+    assert start2 == 7

@@ -1,0 +1,46 @@
+"""Condense the rocprofv3 CSV outputs of tools/profile.sh into one markdown summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def find(pattern):
+    hits = glob.glob(os.path.join(out, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    name = name.replace("void ", "").replace("snr::", "")
+    return name.split("(")[0][:60]
+
+
+print(f"# rocprofv3 summary `{tag}` — `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-frame`\n")
+stats = find(f"{tag}_trace/**/*kernel_stats.csv")
+if stats:
+    print("## kernel trace (--kernel-trace --stats), all 13 steps incl. warm-up and the profiled repeat\n")
+    print("| kernel | calls | total ms | avg us | % |")
+    print("|---|---|---|---|---|")
+    for i, r in enumerate(csv.DictReader(open(stats))):
+        if i >= 16:
+            break
+        print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
+              f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
+for kind, title in (("pmc_sq", "SQ counters (avg per launch)"), ("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    f = find(f"{tag}_{kind}/**/*counter_collection.csv")
+    if not f:
+        continue
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if "mlp_" in k:
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    print(f"\n## {title}\n")
+    for k in sorted(acc):
+        vals = ", ".join(f"{c}={sum(v) / len(v):.4g}" for c, v in sorted(acc[k].items()))
+        print(f"- `{k}` (n={len(next(iter(acc[k].values())))}): {vals}")
+print("\nFETCH_SIZE / WRITE_SIZE are in KiB per launch as reported; per MI355X_MICROARCH.md the read side of a wide "
+      "coalesced stream is under-reported 2x on gfx950 (double FETCH_SIZE before comparing with byte counts).")
