@@ -44,110 +44,127 @@ __global__ __launch_bounds__(64 * Prec<P>::WAVES) void mlp_dgrad_kernel(DgradArg
   using B = Blob<P>;
   using M = Mma<P>;
   using Frag = typename M::Frag;
-  constexpr int FPT = Prec<P>::FPT, EPF = Prec<P>::EPF;
+  constexpr int FPT = Prec<P>::FPT, EPF = Prec<P>::EPF, NJ = ChainNJ<P, true>::value, WAVES = Prec<P>::WAVES;
   constexpr int KS_H = B::KS_H, KS_H9 = B::KS_H9;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, g = lane >> 5;
+  const int sj = lane & 31, g = lane >> 5;
 
-  constexpr int FIRST_KS = 1;  // both variants start with the OUT frag
   Pipe<P> pipe;
   pipe.init(smem, a.blob_bwd, a.bwd_blocks, wave, lane);
 
   const ActLayout<P> AL(a.n_samples, VD);
   const WsLayout<P> WL(a.n_samples, VD);
-  const int64_t n_wg = AL.n_tiles / Prec<P>::WAVES;
-  auto nop = []() {};
+  const int64_t n_wg = AL.n_tiles / (WAVES * NJ);
   const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I4 = std::integral_constant<int, 4>;
+  using I8 = std::integral_constant<int, 8>;
+  using IH = std::integral_constant<int, KS_H>;
+  using IH9 = std::integral_constant<int, KS_H9>;
 
   for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
-    const bool more = wg + gridDim.x < n_wg;
-    const int64_t tile = wg * Prec<P>::WAVES + wave;
-    const int64_t m = tile * 32 + j;
-    const bool valid = m < a.n_samples;
+    const int64_t tile0 = (wg * WAVES + wave) * NJ;
 
-    // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section: tile nt's share of the deferred stores
-    auto ws_store = [&](int64_t sec_off, int n, const Frag* src, int nt, int NT) {
-      char* base = a.ws + sec_off + (tile * n) * 1024 + g * 16;
+    // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section for every sample tile of this wave
+    auto ws_store = [&](int64_t sec_off, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
+      constexpr int n = decltype(N_)::value, stride = decltype(STRIDE_)::value, NT = decltype(NT_)::value;
 #pragma unroll
-      for (int f = 0; f < 64; ++f)
-        if (f >= n * nt / NT && f < n * (nt + 1) / NT) *(Frag*)(base + f * 1024 + act_row<P>(j, f) * 32) = src[f];
+      for (int jt = 0; jt < NJ; ++jt) {
+        char* base = a.ws + sec_off + ((tile0 + jt) * n) * 1024 + g * 16;
+#pragma unroll
+        for (int f = 0; f < n; ++f)
+          if (f >= n * nt / NT && f < n * (nt + 1) / NT)
+            *(Frag*)(base + f * 1024 + act_row<P>(sj, f) * 32) = src[jt * stride + f];
+      }
     };
-    auto mask_load = [&](int64_t sec_off) {
-      return *(const u32x4*)(a.act + sec_off + tile * 1024 + lane * 16);
+    auto mask_load = [&](int64_t sec_off, u32x4* mk) {
+#pragma unroll
+      for (int jt = 0; jt < NJ; ++jt) mk[jt] = *(const u32x4*)(a.act + sec_off + (tile0 + jt) * 1024 + lane * 16);
     };
 
     // ---- d raw -> OUT frag (bf16: k-slot 8g+e = channel; fp32: k-slot g of step e = channel 2e+g)
-    Frag dout = M::zero();
-    if (valid) {
-      const float* dr = a.d_raw + m * a.out_ch;
+    Frag dout[NJ];
 #pragma unroll
-      for (int e = 0; e < EPF; ++e) {
-        const int ch = (P == kBF16) ? 8 * g + e : 2 * e + g;
-        if (ch < a.out_ch) M::set(dout, e, dr[ch]);
+    for (int jt = 0; jt < NJ; ++jt) {
+      dout[jt] = M::zero();
+      const int64_t m = (tile0 + jt) * 32 + sj;
+      if (m < a.n_samples) {
+        const float* dr = a.d_raw + m * a.out_ch;
+#pragma unroll
+        for (int e = 0; e < EPF; ++e) {
+          const int ch = (P == kBF16) ? 8 * g + e : 2 * e + g;
+          if (ch < a.out_ch) M::set(dout[jt], e, dr[ch]);
+        }
       }
     }
 
-    Frag hA[KS_H], hB[KS_H];
-    u32x4 mk_cur, mk_next;
+    Frag hA[NJ][KS_H], hB[NJ][KS_H];
+    u32x4 mk_cur[NJ], mk_next[NJ];
+    auto roll_masks = [&]() {
+#pragma unroll
+      for (int jt = 0; jt < NJ; ++jt) mk_cur[jt] = mk_next[jt];
+    };
 
     // generic stage: dst = mask * (W^T [sa|sb]); NT output tiles
-    auto stage = [&](auto KA_, auto KB_, auto NT_, const Frag* sa, const Frag* sb, Frag* dst, bool use_mask,
-                     int next_ks, bool wrap_last, auto&& pre) {
+    auto stage = [&](auto KA_, auto KB_, auto NT_, auto SA_, auto SB_, const Frag* sa, const Frag* sb, Frag* dst,
+                     bool use_mask, auto&& pre) {
       constexpr int KA = decltype(KA_)::value, KB = decltype(KB_)::value, NT = decltype(NT_)::value;
-      const u32x4 mk = mk_cur;
-      pipe.template run_tiles<KA, KB, NT>(
+      constexpr int SA = decltype(SA_)::value, SB = decltype(SB_)::value;
+      pipe.template run_tiles<KA, KB, NT, NJ, SA, SB>(
           sa, sb, [&](int) { return zero16; },
-          [&](int nt, f32x16 acc) {
+          [&](int nt, int jt, f32x16 acc) {
             if (use_mask) {
-              const unsigned bits = mk[nt >> 1] >> (16 * (nt & 1));
+              const unsigned bits = mk_cur[jt][nt >> 1] >> (16 * (nt & 1));
 #pragma unroll
               for (int r = 0; r < 16; ++r) acc[r] = ((bits >> r) & 1u) ? acc[r] : 0.f;
             }
-            acc_to_frags<P>(acc, dst + nt * FPT);
+            acc_to_frags<P>(acc, dst + jt * KS_H + nt * FPT);
           },
           pre);
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I4 = std::integral_constant<int, 4>;
-    using I8 = std::integral_constant<int, 8>;
-    using IH = std::integral_constant<int, KS_H>;
-    using IH9 = std::integral_constant<int, KS_H9>;
 
     if constexpr (VD) {
-      mk_cur = mask_load(AL.off_mask9());
-      mk_next = mask_load(AL.off_mask(7));
-      // d z9 = relu'(h9) * (W_rgb^T d rgb)                 -> hB[0..KS_H9)
-      stage(I1{}, I0{}, I4{}, &dout, &dout, hB, true, KS_H9, false, [&](int nt) { ws_store(WL.off_dout(), 1, &dout, nt, 4); });
+      mask_load(AL.off_mask9(), mk_cur);
+      mask_load(AL.off_mask(7), mk_next);
+      // d z9 = relu'(h9) * (W_rgb^T d rgb)                 -> hB[.][0..KS_H9)
+      stage(I1{}, I0{}, I4{}, I1{}, I1{}, &dout[0], &dout[0], &hB[0][0], true,
+            [&](int nt) { ws_store(WL.off_dout(), I1{}, &dout[0], I1{}, nt, I4{}); });
       // d feat = W_views[:, :256]^T d z9                    -> hA
-      stage(IH9{}, I0{}, I8{}, hB, hB, hA, false, KS_H + 1, false, [&](int nt) { ws_store(WL.off_dz9(), KS_H9, hB, nt, 8); });
+      stage(IH9{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], false,
+            [&](int nt) { ws_store(WL.off_dz9(), IH9{}, &hB[0][0], IH{}, nt, I8{}); });
       // d z7 = relu'(h7) * (W_feat^T d feat + W_alpha^T d alpha) -> hB
-      mk_cur = mk_next;
-      mk_next = mask_load(AL.off_mask(6));
-      stage(IH{}, I1{}, I8{}, hA, &dout, hB, true, KS_H, false, [&](int nt) { ws_store(WL.off_dfeat(), KS_H, hA, nt, 8); });
+      roll_masks();
+      mask_load(AL.off_mask(6), mk_next);
+      stage(IH{}, I1{}, I8{}, IH{}, I1{}, &hA[0][0], &dout[0], &hB[0][0], true,
+            [&](int nt) { ws_store(WL.off_dfeat(), IH{}, &hA[0][0], IH{}, nt, I8{}); });
     } else {
-      mk_cur = mask_load(AL.off_mask(7));
-      mk_next = mask_load(AL.off_mask(6));
+      mask_load(AL.off_mask(7), mk_cur);
+      mask_load(AL.off_mask(6), mk_next);
       // d z7 = relu'(h7) * (W_out^T d raw)                  -> hB
-      stage(I1{}, I0{}, I8{}, &dout, &dout, hB, true, KS_H, false, [&](int nt) { ws_store(WL.off_dout(), 1, &dout, nt, 8); });
+      stage(I1{}, I0{}, I8{}, I1{}, I1{}, &dout[0], &dout[0], &hB[0][0], true,
+            [&](int nt) { ws_store(WL.off_dout(), I1{}, &dout[0], I1{}, nt, I8{}); });
     }
     // d z_{i-1} = relu'(h_{i-1}) * (W_i^T d z_i), i = 7..1 ; d z7 is in hB
     for (int it = 0; it < 3; ++it) {
       const int i = 7 - 2 * it;  // consumes d z_i from hB
-      mk_cur = mk_next;
-      mk_next = mask_load(AL.off_mask(i - 2));
-      stage(IH{}, I0{}, I8{}, hB, hB, hA, true, KS_H, false, [&](int nt) { ws_store(WL.off_dz(i), KS_H, hB, nt, 8); });
-      mk_cur = mk_next;
-      mk_next = mask_load(AL.off_mask(i - 3 >= 0 ? i - 3 : 0));
-      stage(IH{}, I0{}, I8{}, hA, hA, hB, true, KS_H, false, [&](int nt) { ws_store(WL.off_dz(i - 1), KS_H, hA, nt, 8); });
+      roll_masks();
+      mask_load(AL.off_mask(i - 2), mk_next);
+      stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], true,
+            [&](int nt) { ws_store(WL.off_dz(i), IH{}, &hB[0][0], IH{}, nt, I8{}); });
+      roll_masks();
+      mask_load(AL.off_mask(i - 3 >= 0 ? i - 3 : 0), mk_next);
+      stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], true,
+            [&](int nt) { ws_store(WL.off_dz(i - 1), IH{}, &hA[0][0], IH{}, nt, I8{}); });
     }
-    // i = 1: d z0 from d z1 (hB) -> hA; prefetch wraps to the first chunk for the next tile
-    mk_cur = mk_next;
-    stage(IH{}, I0{}, I8{}, hB, hB, hA, true, more ? FIRST_KS : 0, more, [&](int nt) { ws_store(WL.off_dz(1), KS_H, hB, nt, 8); });
-    ws_store(WL.off_dz(0), KS_H, hA, 0, 1);
+    // i = 1: d z0 from d z1 (hB) -> hA
+    roll_masks();
+    stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], true,
+          [&](int nt) { ws_store(WL.off_dz(1), IH{}, &hB[0][0], IH{}, nt, I8{}); });
+    ws_store(WL.off_dz(0), IH{}, &hA[0][0], IH{}, 0, I1{});
   }
   pipe.drain();
 }

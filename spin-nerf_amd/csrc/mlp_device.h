@@ -90,18 +90,20 @@ template <int P> struct Pipe {
 
   __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-  // NT output tiles of one stage, each KA + KB MFMA groups against the two register sources.
-  //  * weight fragments come through a rolling window of G registers that runs ahead of the MFMAs
-  //    across tile boundaries (the stage starts block-aligned, so block crossings are static);
-  //  * init(nt) supplies the initial accumulator (bias), finish(nt, acc) the epilogue; the epilogue
-  //    of tile nt-1 is placed behind the first MFMA of tile nt so that its VALU work sits in the
-  //    shadow of that tile's dependent MFMA chain (one wave per SIMD: nothing else would hide it);
+  // NT output tiles of one stage for NJ sample tiles at once; each output tile is KA + KB MFMA groups
+  // per sample tile against two register sources (tile j's sources start at sa + j*SA, sb + j*SB).
+  //  * every weight fragment is read from LDS once and feeds NJ MFMAs (independent accumulators);
+  //  * fragments come through a rolling window of G registers that runs ahead of the MFMAs across
+  //    output-tile boundaries (the stage starts block-aligned, so block crossings are static);
+  //  * init(nt) supplies the initial accumulator (bias), finish(nt, j, acc) the epilogue; the epilogues
+  //    of output tile nt-1 are placed behind the first MFMAs of tile nt so that their VALU work sits
+  //    in the shadow of that tile's MFMA chain (one wave per SIMD: nothing else would hide it);
   //  * pre(nt) issues tile nt's slice of the deferred global stores (the previous stage's output):
   //    spread over the tiles so that no burst of stores sits in front of the counted DMA waits.
-  template <int KA, int KB, int NT, class Init, class Finish, class Pre>
+  template <int KA, int KB, int NT, int NJ, int SA, int SB, class Init, class Finish, class Pre>
   __device__ __forceinline__ void run_tiles(const Frag* sa, const Frag* sb, Init&& init, Finish&& finish, Pre&& pre) {
     constexpr int K = KA + KB, NF = NT * K;
-    constexpr int G = (P == kBF16) ? 8 : 4;
+    constexpr int G = (P == kBF16 && NJ == 1) ? 8 : 4;
     Frag w[G];
     auto load = [&](int i) {
       if (i % BF == 0) acquire();
@@ -117,25 +119,33 @@ template <int P> struct Pipe {
 #endif
 #pragma unroll
     for (int i = 0; i < (G < NF ? G : NF); ++i) load(i);
-    f32x16 prev;
+    f32x16 prev[NJ];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      f32x16 acc = init(nt);
+      f32x16 acc[NJ];
+      const f32x16 b0 = init(nt);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[j] = b0;
 #pragma unroll
       for (int f = 0; f < K; ++f) {
         const int i = nt * K + f;
-        acc = M::mma(w[i % G], f < KA ? sa[f < KA ? f : 0] : sb[f < KA ? 0 : f - KA], acc);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[j] = M::mma(w[i % G], f < KA ? sa[j * SA + (f < KA ? f : 0)] : sb[j * SB + (f < KA ? 0 : f - KA)], acc[j]);
         if (i + G < NF) load(i + G);
         if (f == 0) {
           pre(nt);   // this tile's slice of the deferred global stores
-#if SNR_ABLATE != 3
-          if (nt > 0) finish(nt - 1, prev);
-#endif
+          if (nt > 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) finish(nt - 1, j, prev[j]);
+          }
         }
       }
-      prev = acc;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) prev[j] = acc[j];
     }
-    finish(NT - 1, prev);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) finish(NT - 1, j, prev[j]);
   }
 };
 

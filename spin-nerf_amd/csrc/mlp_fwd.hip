@@ -99,177 +99,212 @@ __global__ __launch_bounds__(64 * Prec<P>::WAVES) void mlp_fwd_kernel(FwdArgs a)
   using B = Blob<P>;
   using M = Mma<P>;
   using Frag = typename M::Frag;
-  constexpr int FPT = Prec<P>::FPT;
+  constexpr int FPT = Prec<P>::FPT, NJ = ChainNJ<P, TRAIN>::value, WAVES = Prec<P>::WAVES;
   constexpr int KS_H = B::KS_H, KS_PE = B::KS_PE, KS_DIR = B::KS_DIR, KS_H9 = B::KS_H9;
+  constexpr int KS_DIRA = VD ? KS_DIR : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, g = lane >> 5;
+  const int sj = lane & 31, g = lane >> 5;   // sample within a 32-sample tile, lane half
 
-  for (int i = tid; i < a.bias_floats; i += 64 * Prec<P>::WAVES) bias_lds[i] = a.bias[i];
+  for (int i = tid; i < a.bias_floats; i += 64 * WAVES) bias_lds[i] = a.bias[i];
 
   Pipe<P> pipe;
   pipe.init(smem + kBiasLdsBytes, a.blob, a.fwd_blocks, wave, lane);
   __syncthreads();  // bias block visible to all waves
 
   const ActLayout<P> AL(a.n_samples, VD);
-  const int64_t n_wg = AL.n_tiles / Prec<P>::WAVES;
-  auto nop = []() {};
+  const int64_t n_wg = (AL.n_tiles + WAVES * NJ - 1) / (WAVES * NJ);   // tail tiles beyond n_samples are masked by `valid`
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using IPE = std::integral_constant<int, KS_PE>;
+  using IH = std::integral_constant<int, KS_H>;
+  using IDIR = std::integral_constant<int, KS_DIR>;
+  using IDIRA = std::integral_constant<int, KS_DIRA>;
 
   for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
-    const bool more = wg + gridDim.x < n_wg;
-    const int64_t tile = wg * Prec<P>::WAVES + wave;
-    const int64_t m = tile * 32 + j;
-    const bool valid = m < a.n_samples;
-    const int64_t ray = valid ? m / a.S : 0;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (valid) {
-      if (a.pts) {
-        x = a.pts[3 * m]; y = a.pts[3 * m + 1]; z = a.pts[3 * m + 2];
-      } else {
-        const float* r = a.rays + ray * a.ray_ld;
-        const float t = a.z_vals[m];
-        // run_nerf.py:670-671; separate multiply and add (no FMA) so pts round like the reference's
-        x = mul_add_unfused(r[3], t, r[0]);
-        y = mul_add_unfused(r[4], t, r[1]);
-        z = mul_add_unfused(r[5], t, r[2]);
+    const int64_t tile0 = (wg * WAVES + wave) * NJ;   // this wave's first 32-sample tile
+    int64_t m[NJ];
+    bool valid[NJ];
+    Frag pe[NJ][KS_PE];
+    Frag dir[NJ][KS_DIRA];
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+      m[jt] = (tile0 + jt) * 32 + sj;
+      valid[jt] = m[jt] < a.n_samples;
+      const int64_t ray = valid[jt] ? m[jt] / a.S : 0;
+      float x = 0.f, y = 0.f, z = 0.f;
+      if (valid[jt]) {
+        if (a.pts) {
+          x = a.pts[3 * m[jt]]; y = a.pts[3 * m[jt] + 1]; z = a.pts[3 * m[jt] + 2];
+        } else {
+          const float* r = a.rays + ray * a.ray_ld;
+          const float t = a.z_vals[m[jt]];
+          // run_nerf.py:670-671; separate multiply and add (no FMA) so pts round like the reference's
+          x = mul_add_unfused(r[3], t, r[0]);
+          y = mul_add_unfused(r[4], t, r[1]);
+          z = mul_add_unfused(r[5], t, r[2]);
+        }
       }
-    }
-    Frag pe[KS_PE];
-    encode<P, KS_PE>(x, y, z, a.multires, g, pe);
-    Frag dir[VD ? KS_DIR : 1];
-    if constexpr (VD) {
-      float dx = 0.f, dy = 0.f, dz = 0.f;
-      if (valid) {
-        const float* v = a.viewdirs + ray * a.vd_ld;
-        dx = v[0]; dy = v[1]; dz = v[2];
+      encode<P, KS_PE>(x, y, z, a.multires, g, pe[jt]);
+      if constexpr (VD) {
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (valid[jt]) {
+          const float* v = a.viewdirs + ray * a.vd_ld;
+          dx = v[0]; dy = v[1]; dz = v[2];
+        }
+        encode<P, KS_DIR>(dx, dy, dz, a.multires_views, g, dir[jt]);
       }
-      encode<P, KS_DIR>(dx, dy, dz, a.multires_views, g, dir);
     }
 
-    // per-lane byte offset inside a [tile][ks][32][32B] section
-    // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section: tile nt's share of the deferred stores
-    auto act_store = [&](int64_t sec_off, int n, const Frag* src, int nt, int NT) {
-      char* base = a.act + sec_off + (tile * n) * 1024 + g * 16;
+    // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section, for every sample tile of this wave: output tile
+    // nt's share of the deferred stores.  Section layout [tile][frag][32 samples][32 B].
+    auto act_store = [&](int64_t sec_off, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
+      constexpr int n = decltype(N_)::value, stride = decltype(STRIDE_)::value, NT = decltype(NT_)::value;
 #pragma unroll
-      for (int f = 0; f < 16 * 4; ++f)
-        if (f >= n * nt / NT && f < n * (nt + 1) / NT) *(Frag*)(base + f * 1024 + act_row<P>(j, f) * 32) = src[f];
+      for (int jt = 0; jt < NJ; ++jt) {
+        char* base = a.act + sec_off + ((tile0 + jt) * n) * 1024 + g * 16;
+#pragma unroll
+        for (int f = 0; f < n; ++f)
+          if (f >= n * nt / NT && f < n * (nt + 1) / NT)
+            *(Frag*)(base + f * 1024 + act_row<P>(sj, f) * 32) = src[jt * stride + f];
+      }
+    };
+    using I4 = std::integral_constant<int, 4>;
+    using I8 = std::integral_constant<int, 8>;
+    using I9 = std::integral_constant<int, 9>;
+    using IH9 = std::integral_constant<int, KS_H9>;
+    auto mask_store = [&](int64_t sec_off, const u32x4* mk) {
+#pragma unroll
+      for (int jt = 0; jt < NJ; ++jt) *(u32x4*)(a.act + sec_off + (tile0 + jt) * 1024 + lane * 16) = mk[jt];
     };
 
-    Frag hA[KS_H], hB[KS_H];
-    u32x4 mask = {0, 0, 0, 0};
+    Frag hA[NJ][KS_H], hB[NJ][KS_H];
+    u32x4 mask[NJ];
 
-    // ---- generic stage: dst = [relu](W [sa|sb] + b), NT output tiles ----
-    auto relu_mask = [&](int nt, f32x16& acc) {
+    auto relu_mask = [&](int nt, int jt, f32x16& acc) {
       unsigned bits = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         bits |= (acc[r] > 0.f ? 1u : 0u) << r;
         acc[r] = fmaxf(acc[r], 0.f);
       }
-      if constexpr (TRAIN) mask[nt >> 1] |= bits << (16 * (nt & 1));
+      if constexpr (TRAIN) mask[jt][nt >> 1] |= bits << (16 * (nt & 1));
     };
-    auto stage8 = [&](auto KA_, auto KB_, const Frag* sa, const Frag* sb, Frag* dst, int bias_off, int next_ks,
+    auto clear_masks = [&]() {
+#pragma unroll
+      for (int jt = 0; jt < NJ; ++jt) mask[jt] = u32x4{0, 0, 0, 0};
+    };
+    // ---- generic 8-tile stage: dst = [relu](W [sa|sb] + b); sources / dst have per-sample-tile strides ----
+    auto stage8 = [&](auto KA_, auto KB_, auto SA_, auto SB_, const Frag* sa, const Frag* sb, Frag* dst, int bias_off,
                       bool relu, auto&& pre) {
       constexpr int KA = decltype(KA_)::value, KB = decltype(KB_)::value;
-      mask = u32x4{0, 0, 0, 0};
-      pipe.template run_tiles<KA, KB, 8>(
+      constexpr int SA = decltype(SA_)::value, SB = decltype(SB_)::value;
+      clear_masks();
+      pipe.template run_tiles<KA, KB, 8, NJ, SA, SB>(
           sa, sb, [&](int nt) { return bias_tile(bias_lds, bias_off + 32 * nt, g); },
-          [&](int nt, f32x16 acc) {
-            if (relu) relu_mask(nt, acc);
-            acc_to_frags<P>(acc, dst + nt * FPT);
+          [&](int nt, int jt, f32x16 acc) {
+            if (relu) relu_mask(nt, jt, acc);
+            acc_to_frags<P>(acc, dst + jt * KS_H + nt * FPT);
           },
           pre);
     };
-    using I0 = std::integral_constant<int, 0>;
-    using IPE = std::integral_constant<int, KS_PE>;
-    using IH = std::integral_constant<int, KS_H>;
-    using IDIR = std::integral_constant<int, KS_DIR>;
-
-    auto mask_store = [&](int64_t sec_off, const u32x4& mk) {
-      *(u32x4*)(a.act + sec_off + tile * 1024 + lane * 16) = mk;
-    };
 
     // stage 0: PE -> hA
-    stage8(IPE{}, I0{}, pe, pe, hA, bias_off_stage(0), KS_H, true, [&](int nt) {
+    stage8(IPE{}, I0{}, IPE{}, IPE{}, &pe[0][0], &pe[0][0], &hA[0][0], bias_off_stage(0), true, [&](int nt) {
       if constexpr (TRAIN) {
-        act_store(AL.off_pe(), KS_PE, pe, nt, 8);
-        if constexpr (VD) act_store(AL.off_dir(), KS_DIR, dir, nt, 8);
+        act_store(AL.off_pe(), IPE{}, &pe[0][0], IPE{}, nt, I8{});
+        if constexpr (VD) act_store(AL.off_dir(), IDIR{}, &dir[0][0], IDIRA{}, nt, I8{});
       }
     });
     // stages 1..7 ping-pong hA/hB; stage 5 prepends the encoding (skip connection, helpers:110-111)
+    u32x4 pmask[NJ];
+    auto keep_masks = [&]() {
+#pragma unroll
+      for (int jt = 0; jt < NJ; ++jt) pmask[jt] = mask[jt];
+    };
     auto pre_of = [&](int s_prev, const Frag* src) {
-      const u32x4 pmask = mask;
-      return [&, s_prev, src, pmask](int nt) {
+      return [&, s_prev, src](int nt) {
         if constexpr (TRAIN) {
-          act_store(AL.off_h(s_prev), KS_H, src, nt, 8);
+          act_store(AL.off_h(s_prev), IH{}, src, IH{}, nt, I8{});
           if (nt == 0) mask_store(AL.off_mask(s_prev), pmask);
         }
       };
     };
     for (int it = 0; it < 2; ++it) {  // stages (1,2), (3,4)
       const int s1 = 1 + 2 * it;
-      stage8(I0{}, IH{}, hA, hA, hB, bias_off_stage(s1), KS_H, true, pre_of(s1 - 1, hA));
-      stage8(I0{}, IH{}, hB, hB, hA, bias_off_stage(s1 + 1), it == 1 ? KS_PE + KS_H : KS_H, true, pre_of(s1, hB));
+      keep_masks();
+      stage8(I0{}, IH{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], bias_off_stage(s1), true, pre_of(s1 - 1, &hA[0][0]));
+      keep_masks();
+      stage8(I0{}, IH{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], bias_off_stage(s1 + 1), true, pre_of(s1, &hB[0][0]));
     }
-    stage8(IPE{}, IH{}, pe, hA, hB, bias_off_stage(5), KS_H, true, pre_of(4, hA));
-    stage8(I0{}, IH{}, hB, hB, hA, bias_off_stage(6), KS_H, true, pre_of(5, hB));
-    stage8(I0{}, IH{}, hA, hA, hB, bias_off_stage(7), KS_H, true, pre_of(6, hA));
-    Frag* cur = hB;
-    Frag* nxt = hA;
-    // cur = h7 (hB), nxt = hA
-    const u32x4 mask7 = mask;
+    keep_masks();
+    stage8(IPE{}, IH{}, IPE{}, IH{}, &pe[0][0], &hA[0][0], &hB[0][0], bias_off_stage(5), true, pre_of(4, &hA[0][0]));
+    keep_masks();
+    stage8(I0{}, IH{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], bias_off_stage(6), true, pre_of(5, &hB[0][0]));
+    keep_masks();
+    stage8(I0{}, IH{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], bias_off_stage(7), true, pre_of(6, &hA[0][0]));
+    keep_masks();   // masks of stage 7
+    Frag* cur = &hB[0][0];   // h7
+    Frag* nxt = &hA[0][0];
     if constexpr (VD) {
       // stage 8: feature (8 tiles, no relu) + the alpha tile (row 0 = alpha_linear)
-      float alpha = 0.f;
-      pipe.template run_tiles<0, KS_H, 9>(
+      float alpha[NJ];
+      pipe.template run_tiles<0, KS_H, 9, NJ, KS_H, KS_H>(
           cur, cur, [&](int nt) { return bias_tile(bias_lds, kBiasFeat + 32 * nt, g); },
-          [&](int nt, f32x16 acc) {
-            if (nt < 8) acc_to_frags<P>(acc, nxt + nt * FPT);
-            else alpha = acc[0];  // row 0 lives in register 0 of lanes 0..31
+          [&](int nt, int jt, f32x16 acc) {
+            if (nt < 8) acc_to_frags<P>(acc, nxt + jt * KS_H + nt * FPT);
+            else alpha[jt] = acc[0];  // row 0 lives in register 0 of lanes 0..31
           },
           [&](int nt) {
             if constexpr (TRAIN) {
-              act_store(AL.off_h(7), KS_H, cur, nt, 9);
-              if (nt == 0) mask_store(AL.off_mask(7), mask7);
+              act_store(AL.off_h(7), IH{}, cur, IH{}, nt, I9{});
+              if (nt == 0) mask_store(AL.off_mask(7), pmask);
             }
           });
       // stage 9: views = relu(W [feat | dir] + b), 4 tiles -> h9 (in `cur` storage)
       Frag* feat = nxt;
       Frag* h9 = cur;
-      mask = u32x4{0, 0, 0, 0};
-      pipe.template run_tiles<KS_H, KS_DIR, 4>(
-          feat, dir, [&](int nt) { return bias_tile(bias_lds, kBiasViews + 32 * nt, g); },
-          [&](int nt, f32x16 acc) {
-            relu_mask(nt, acc);
-            acc_to_frags<P>(acc, h9 + nt * FPT);
+      clear_masks();
+      pipe.template run_tiles<KS_H, KS_DIR, 4, NJ, KS_H, KS_DIRA>(
+          feat, &dir[0][0], [&](int nt) { return bias_tile(bias_lds, kBiasViews + 32 * nt, g); },
+          [&](int nt, int jt, f32x16 acc) {
+            relu_mask(nt, jt, acc);
+            acc_to_frags<P>(acc, h9 + jt * KS_H + nt * FPT);
           },
           [&](int nt) {
-            if constexpr (TRAIN) act_store(AL.off_feat(), KS_H, feat, nt, 4);
+            if constexpr (TRAIN) act_store(AL.off_feat(), IH{}, feat, IH{}, nt, I4{});
           });
       // stage 10: rgb
-      const u32x4 mask9 = mask;
-      f32x16 acc_c;
-      pipe.template run_tiles<0, KS_H9, 1>(
-          h9, h9, [&](int) { return bias_tile(bias_lds, kBiasRgb, g); }, [&](int, f32x16 acc) { acc_c = acc; },
+      keep_masks();
+      f32x16 acc_c[NJ];
+      pipe.template run_tiles<0, KS_H9, 1, NJ, KS_H, KS_H>(
+          h9, h9, [&](int) { return bias_tile(bias_lds, kBiasRgb, g); },
+          [&](int, int jt, f32x16 acc) { acc_c[jt] = acc; },
           [&](int) {
-            if constexpr (TRAIN) { act_store(AL.off_h9(), KS_H9, h9, 0, 1); mask_store(AL.off_mask9(), mask9); }
+            if constexpr (TRAIN) { act_store(AL.off_h9(), IH9{}, h9, IH{}, 0, I1{}); mask_store(AL.off_mask9(), pmask); }
           });
-      if (valid && g == 0) *(f32x4*)(a.raw + 4 * m) = f32x4{acc_c[0], acc_c[1], acc_c[2], alpha};
+#pragma unroll
+      for (int jt = 0; jt < NJ; ++jt)
+        if (valid[jt] && g == 0) *(f32x4*)(a.raw + 4 * m[jt]) = f32x4{acc_c[jt][0], acc_c[jt][1], acc_c[jt][2], alpha[jt]};
     } else {
-      f32x16 acc_o;
-      pipe.template run_tiles<0, KS_H, 1>(
-          cur, cur, [&](int) { return bias_tile(bias_lds, kBiasOut, g); }, [&](int, f32x16 acc) { acc_o = acc; },
+      f32x16 acc_o[NJ];
+      pipe.template run_tiles<0, KS_H, 1, NJ, KS_H, KS_H>(
+          cur, cur, [&](int) { return bias_tile(bias_lds, kBiasOut, g); },
+          [&](int, int jt, f32x16 acc) { acc_o[jt] = acc; },
           [&](int) {
-            if constexpr (TRAIN) { act_store(AL.off_h(7), KS_H, cur, 0, 1); mask_store(AL.off_mask(7), mask7); }
+            if constexpr (TRAIN) { act_store(AL.off_h(7), IH{}, cur, IH{}, 0, I1{}); mask_store(AL.off_mask(7), pmask); }
           });
       // rows 0..3 = registers 0..3 of lane half 0; row 4 = register 0 of lane half 1
-      if (valid) {
-        float* o = a.raw + (int64_t)a.out_ch * m;
-        if (g == 0) { o[0] = acc_o[0]; o[1] = acc_o[1]; o[2] = acc_o[2]; o[3] = acc_o[3]; }
-        else if (a.out_ch == 5) o[4] = acc_o[0];
+#pragma unroll
+      for (int jt = 0; jt < NJ; ++jt) {
+        if (valid[jt]) {
+          float* o = a.raw + (int64_t)a.out_ch * m[jt];
+          if (g == 0) { o[0] = acc_o[jt][0]; o[1] = acc_o[jt][1]; o[2] = acc_o[jt][2]; o[3] = acc_o[jt][3]; }
+          else if (a.out_ch == 5) o[4] = acc_o[jt][0];
+        }
       }
     }
   }
@@ -338,7 +373,8 @@ extern "C" int snr_mlp_pack(const snr_mlp_config* c, const float* params, void* 
 
 template <int P, bool VD, bool TRAIN>
 static int launch_fwd(const FwdArgs& a, hipStream_t s) {
-  const int64_t n_wg = padded_tiles<P>(a.n_samples) / Prec<P>::WAVES;
+  constexpr int per_wg = Prec<P>::WAVES * ChainNJ<P, TRAIN>::value;
+  const int64_t n_wg = (padded_tiles<P>(a.n_samples) + per_wg - 1) / per_wg;
   const int lds = kBiasLdsBytes + kRingBytes;
   static bool attr_set = false;
   if (!attr_set) {

@@ -43,13 +43,22 @@ enum Precision { kBF16 = 0, kFP32 = 1 };
 
 template <int P> struct Prec;
 // WAVES = waves per workgroup of the chained kernels (forward, dgrad): one per SIMD, each with the
-// whole 512-entry VGPR+AGPR file (two 64-register activation sets + encodings + a rolling weight
-// window do not fit the 256 registers that two waves per SIMD would leave — measured: ~100 spills).
-template <> struct Prec<kBF16> { static constexpr int EPF = 8, FPT = 2, ESZ = 2, WAVES = 4; };
-template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4, WAVES = 4; };
+// whole 512-entry VGPR+AGPR file.  NJ = 32-sample tiles per wave: with two tiles every weight
+// fragment read from LDS feeds two MFMAs — measured on MI355X, re-reading all 16 fragments of a 16 KiB
+// block from every wave costs ~1040 cycles per block against 512 cycles of MFMA at NJ = 1, i.e. LDS read
+// traffic, not the matrix pipe, paces the chain.  fp32 activations of one tile already take 256
+// registers, so the parity path stays at one tile per wave.
+template <> struct Prec<kBF16> { static constexpr int EPF = 8, FPT = 2, ESZ = 2, WAVES = 4, NJ = 2; };
+template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4, WAVES = 4, NJ = 1; };
+// The training kernels (forward with saved activations, dgrad) run one tile per wave for now: their
+// activation stores share the vmcnt counter with the DMA stream, and at two tiles per wave the
+// conservative counted wait stalls on them (measured: forward 0.39 vs 0.37 ms, dgrad spills).
+template <int P, bool TRAIN> struct ChainNJ { static constexpr int value = TRAIN ? 1 : Prec<P>::NJ; };
+// 32-sample tiles of the saved-activation sections: padded to whole training workgroups
 template <int P> SNR_HD int64_t padded_tiles(int64_t n_samples) {
-  constexpr int wg = kTileSamples * Prec<P>::WAVES;
-  return (n_samples + wg - 1) / wg * Prec<P>::WAVES;
+  constexpr int per_wg = Prec<P>::WAVES;
+  constexpr int wg = kTileSamples * per_wg;
+  return (n_samples + wg - 1) / wg * per_wg;
 }
 
 // ---- k-slot -> neuron maps -------------------------------------------------------------
