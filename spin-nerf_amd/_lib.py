@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspinnerf_hip.so")
+# SNR_LIB overrides the library path (kernel experiments: ablation builds under lib/ablate/)
+LIB_PATH = os.environ.get("SNR_LIB") or os.path.join(_HERE, "lib", "libspinnerf_hip.so")
 
 PREC_BF16, PREC_FP32 = 0, 1
 

@@ -40,11 +40,11 @@ struct DgradArgs {
 };
 
 template <int P, bool VD>
-__global__ __launch_bounds__(64 * Prec<P>::WAVES) void mlp_dgrad_kernel(DgradArgs a) {
+__global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_kernel(DgradArgs a) {
   using B = Blob<P>;
   using M = Mma<P>;
   using Frag = typename M::Frag;
-  constexpr int FPT = Prec<P>::FPT, EPF = Prec<P>::EPF, NJ = ChainNJ<P, true>::value, WAVES = Prec<P>::WAVES;
+  constexpr int FPT = Prec<P>::FPT, EPF = Prec<P>::EPF, NJ = ChainCfg<P, true>::NJ, WAVES = ChainCfg<P, true>::WAVES;
   constexpr int KS_H = B::KS_H, KS_H9 = B::KS_H9;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64 * Prec<P>::WAVES) void mlp_dgrad_kernel(DgradArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int sj = lane & 31, g = lane >> 5;
 
-  Pipe<P> pipe;
+  Pipe<P, WAVES> pipe;
   pipe.init(smem, a.blob_bwd, a.bwd_blocks, wave, lane);
 
   const ActLayout<P> AL(a.n_samples, VD);
@@ -200,7 +200,7 @@ extern "C" int64_t snr_mlp_bwd_ws_bytes(const snr_mlp_config* c, int64_t n) {
 
 template <int P, bool VD>
 static int launch_dgrad(const DgradArgs& a, hipStream_t s) {
-  const int64_t n_wg = padded_tiles<P>(a.n_samples) / Prec<P>::WAVES;
+  const int64_t n_wg = padded_tiles<P>(a.n_samples) / (ChainCfg<P, true>::WAVES * ChainCfg<P, true>::NJ);
   const int lds = kRingBytes;
   static bool attr_set = false;
   if (!attr_set) {
@@ -211,7 +211,7 @@ static int launch_dgrad(const DgradArgs& a, hipStream_t s) {
   const int64_t grid = n_wg < 1024 ? n_wg : 1024;
   {
     ProfScope ps(K_MLP_DGRAD, s);
-    mlp_dgrad_kernel<P, VD><<<dim3((unsigned)grid), dim3(64 * Prec<P>::WAVES), lds, s>>>(a);
+    mlp_dgrad_kernel<P, VD><<<dim3((unsigned)grid), dim3(64 * ChainCfg<P, true>::WAVES), lds, s>>>(a);
   }
   return launch_status();
 }

@@ -44,11 +44,11 @@ constexpr int kRing = 6;
 constexpr int kDepth = 4;    // = kRing - 2: the slot re-filled on entering block b is that of block b-2
 constexpr int kRingBytes = kRing * kBlockFrags * 1024;
 
-template <int P> struct Pipe {
+template <int P, int WAVES_> struct Pipe {
   using M = Mma<P>;
   using Frag = typename M::Frag;
   static constexpr int BF = kBlockFrags, BLOCK = kBlockFrags * 1024;
-  static constexpr int WAVES = Prec<P>::WAVES, PIECES = kBlockFrags / Prec<P>::WAVES;
+  static constexpr int WAVES = WAVES_, PIECES = kBlockFrags / WAVES_;
   char* ring;
   const char* gbase;
   int n_blocks;      // blocks in the cyclic stream
@@ -56,28 +56,45 @@ template <int P> struct Pipe {
   int issue_slot;    // ring slot it will land in
   int cur_slot;      // ring slot of the block being consumed
   int wave, lane;
+  int pend;          // DMA pieces of the block being issued that are still to be issued
+  const char* pend_src;
+  char* pend_dst;
 
   __device__ __forceinline__ void init(char* ring_, const char* gbase_, int n_blocks_, int wave_, int lane_) {
     ring = ring_; gbase = gbase_; n_blocks = n_blocks_; wave = wave_; lane = lane_;
-    issue_blk = 0; issue_slot = 0; cur_slot = kRing - 1;
-    for (int d = 0; d < kDepth; ++d) issue();
+    issue_blk = 0; issue_slot = 0; cur_slot = kRing - 1; pend = 0;
+    for (int d = 0; d < kDepth; ++d) { begin_issue(); flush(); }
   }
 
-  __device__ __forceinline__ void issue() {
-    const char* src = gbase + (int64_t)issue_blk * BLOCK + wave * 1024 + lane * 16;
-    char* dst = ring + issue_slot * BLOCK + wave * 1024;
-#pragma unroll
-    for (int p = 0; p < PIECES; ++p)
-      __builtin_amdgcn_global_load_lds(src + p * WAVES * 1024, SNR_LDS(dst + p * WAVES * 1024), 16, 0, 0);
+  // DMA of the next block of the stream, PIECES instructions per wave.  Measured on MI355X: issued
+  // as a burst right behind the barrier, the 16 DMA instructions of the 4 waves serialise on the CU's
+  // address path and cost every wave ~690 cycles per block (vs 512 cycles of MFMA); dripped one at a
+  // time between MFMAs (issue_one) they hide in the MFMA shadow.
+  __device__ __forceinline__ void begin_issue() {
+    pend_src = gbase + (int64_t)issue_blk * BLOCK + wave * 1024 + lane * 16;
+    pend_dst = ring + issue_slot * BLOCK + wave * 1024;
+    pend = PIECES;
     issue_blk = issue_blk + 1 == n_blocks ? 0 : issue_blk + 1;
     issue_slot = issue_slot + 1 == kRing ? 0 : issue_slot + 1;
   }
+  __device__ __forceinline__ void issue_one() {
+    if (pend > 0) {
+      __builtin_amdgcn_global_load_lds(pend_src, SNR_LDS(pend_dst), 16, 0, 0);
+      pend_src += WAVES * 1024;
+      pend_dst += WAVES * 1024;
+      --pend;
+    }
+  }
+  __device__ __forceinline__ void flush() {
+    while (pend > 0) issue_one();
+  }
 
   __device__ __forceinline__ void acquire() {
-#if SNR_ABLATE >= 1   // timing experiments only (results are garbage): no wait / barrier / DMA
+#if SNR_ABLATE >= 1 && SNR_ABLATE <= 3   // timing experiments only (results are garbage): no wait / barrier / DMA
     cur_slot = cur_slot + 1 == kRing ? 0 : cur_slot + 1;
     return;
 #endif
+    flush();   // the counted wait below assumes every older block is completely issued
     // allowed outstanding = this wave's pieces of the kDepth-1 younger blocks
     static_assert(PIECES * (kDepth - 1) == 6 || PIECES * (kDepth - 1) == 12, "add the immediate");
     if constexpr (PIECES * (kDepth - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -85,10 +102,10 @@ template <int P> struct Pipe {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     cur_slot = cur_slot + 1 == kRing ? 0 : cur_slot + 1;
-    issue();
+    begin_issue();   // pieces follow from the MFMA loop (issue_one)
   }
 
-  __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  __device__ __forceinline__ void drain() { flush(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
   // NT output tiles of one stage for NJ sample tiles at once; each output tile is KA + KB MFMA groups
   // per sample tile against two register sources (tile j's sources start at sa + j*SA, sb + j*SB).
@@ -103,7 +120,8 @@ template <int P> struct Pipe {
   template <int KA, int KB, int NT, int NJ, int SA, int SB, class Init, class Finish, class Pre>
   __device__ __forceinline__ void run_tiles(const Frag* sa, const Frag* sb, Init&& init, Finish&& finish, Pre&& pre) {
     constexpr int K = KA + KB, NF = NT * K;
-    constexpr int G = (P == kBF16 && NJ == 1) ? 8 : 4;
+    constexpr int G = (P == kBF16 && NJ == 1 && WAVES == 4) ? 8 : 4;
+    constexpr bool OVERLAP = WAVES == 4;   // two waves per SIMD overlap each other; no need to hold two accumulators
     Frag w[G];
     auto load = [&](int i) {
       if (i % BF == 0) acquire();
@@ -133,19 +151,27 @@ template <int P> struct Pipe {
         for (int j = 0; j < NJ; ++j)
           acc[j] = M::mma(w[i % G], f < KA ? sa[j * SA + (f < KA ? f : 0)] : sb[j * SB + (f < KA ? 0 : f - KA)], acc[j]);
         if (i + G < NF) load(i + G);
+        if (NJ > 1 || (f & 1)) issue_one();   // one DMA piece per ~64 cycles of MFMA
         if (f == 0) {
           pre(nt);   // this tile's slice of the deferred global stores
-          if (nt > 0) {
+          if (OVERLAP && nt > 0) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) finish(nt - 1, j, prev[j]);
           }
         }
       }
+      if constexpr (OVERLAP) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) prev[j] = acc[j];
+        for (int j = 0; j < NJ; ++j) prev[j] = acc[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) finish(nt, j, acc[j]);
+      }
     }
+    if constexpr (OVERLAP) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) finish(NT - 1, j, prev[j]);
+      for (int j = 0; j < NJ; ++j) finish(NT - 1, j, prev[j]);
+    }
   }
 };
 

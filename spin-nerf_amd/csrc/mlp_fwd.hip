@@ -95,11 +95,11 @@ struct FwdArgs {
 };
 
 template <int P, bool VD, bool TRAIN>
-__global__ __launch_bounds__(64 * Prec<P>::WAVES) void mlp_fwd_kernel(FwdArgs a) {
+__global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kernel(FwdArgs a) {
   using B = Blob<P>;
   using M = Mma<P>;
   using Frag = typename M::Frag;
-  constexpr int FPT = Prec<P>::FPT, NJ = ChainNJ<P, TRAIN>::value, WAVES = Prec<P>::WAVES;
+  constexpr int FPT = Prec<P>::FPT, NJ = ChainCfg<P, TRAIN>::NJ, WAVES = ChainCfg<P, TRAIN>::WAVES;
   constexpr int KS_H = B::KS_H, KS_PE = B::KS_PE, KS_DIR = B::KS_DIR, KS_H9 = B::KS_H9;
   constexpr int KS_DIRA = VD ? KS_DIR : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64 * Prec<P>::WAVES) void mlp_fwd_kernel(FwdArgs a)
 
   for (int i = tid; i < a.bias_floats; i += 64 * WAVES) bias_lds[i] = a.bias[i];
 
-  Pipe<P> pipe;
+  Pipe<P, WAVES> pipe;
   pipe.init(smem + kBiasLdsBytes, a.blob, a.fwd_blocks, wave, lane);
   __syncthreads();  // bias block visible to all waves
 
@@ -128,36 +128,56 @@ __global__ __launch_bounds__(64 * Prec<P>::WAVES) void mlp_fwd_kernel(FwdArgs a)
     const int64_t tile0 = (wg * WAVES + wave) * NJ;   // this wave's first 32-sample tile
     int64_t m[NJ];
     bool valid[NJ];
-    Frag pe[NJ][KS_PE];
-    Frag dir[NJ][KS_DIRA];
+    float px[NJ], py[NJ], pz[NJ], dx[NJ], dy[NJ], dz[NJ];
 #pragma unroll
     for (int jt = 0; jt < NJ; ++jt) {
       m[jt] = (tile0 + jt) * 32 + sj;
       valid[jt] = m[jt] < a.n_samples;
       const int64_t ray = valid[jt] ? m[jt] / a.S : 0;
-      float x = 0.f, y = 0.f, z = 0.f;
+      px[jt] = py[jt] = pz[jt] = dx[jt] = dy[jt] = dz[jt] = 0.f;
       if (valid[jt]) {
         if (a.pts) {
-          x = a.pts[3 * m[jt]]; y = a.pts[3 * m[jt] + 1]; z = a.pts[3 * m[jt] + 2];
+          px[jt] = a.pts[3 * m[jt]]; py[jt] = a.pts[3 * m[jt] + 1]; pz[jt] = a.pts[3 * m[jt] + 2];
         } else {
           const float* r = a.rays + ray * a.ray_ld;
           const float t = a.z_vals[m[jt]];
           // run_nerf.py:670-671; separate multiply and add (no FMA) so pts round like the reference's
-          x = mul_add_unfused(r[3], t, r[0]);
-          y = mul_add_unfused(r[4], t, r[1]);
-          z = mul_add_unfused(r[5], t, r[2]);
+          px[jt] = mul_add_unfused(r[3], t, r[0]);
+          py[jt] = mul_add_unfused(r[4], t, r[1]);
+          pz[jt] = mul_add_unfused(r[5], t, r[2]);
         }
-      }
-      encode<P, KS_PE>(x, y, z, a.multires, g, pe[jt]);
-      if constexpr (VD) {
-        float dx = 0.f, dy = 0.f, dz = 0.f;
-        if (valid[jt]) {
+        if constexpr (VD) {
           const float* v = a.viewdirs + ray * a.vd_ld;
-          dx = v[0]; dy = v[1]; dz = v[2];
+          dx[jt] = v[0]; dy[jt] = v[1]; dz[jt] = v[2];
         }
-        encode<P, KS_DIR>(dx, dy, dz, a.multires_views, g, dir[jt]);
       }
     }
+    // Encodings.  With two waves per SIMD (256 registers each) they are not kept across the trunk:
+    // bf16 re-derives them where they are consumed (hardware sin/cos, ~200 instructions) — `fresh`
+    // hides the inputs from common-subexpression elimination so the first copy really dies.
+    constexpr bool kKeepEnc = WAVES == 4;
+    Frag pe[NJ][KS_PE];
+    Frag dir[NJ][KS_DIRA];
+    auto make_pe = [&](bool fresh) {
+#pragma unroll
+      for (int jt = 0; jt < NJ; ++jt) {
+        float x = px[jt], y = py[jt], z = pz[jt];
+        if (fresh) asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+        encode<P, KS_PE>(x, y, z, a.multires, g, pe[jt]);
+      }
+    };
+    auto make_dir = [&](bool fresh) {
+      if constexpr (VD) {
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+          float x = dx[jt], y = dy[jt], z = dz[jt];
+          if (fresh) asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+          encode<P, KS_DIR>(x, y, z, a.multires_views, g, dir[jt]);
+        }
+      }
+    };
+    make_pe(false);
+    if (TRAIN || kKeepEnc) make_dir(false);
 
     // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section, for every sample tile of this wave: output tile
     // nt's share of the deferred stores.  Section layout [tile][frag][32 samples][32 B].
@@ -241,6 +261,7 @@ __global__ __launch_bounds__(64 * Prec<P>::WAVES) void mlp_fwd_kernel(FwdArgs a)
       stage8(I0{}, IH{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], bias_off_stage(s1 + 1), true, pre_of(s1, &hB[0][0]));
     }
     keep_masks();
+    if (!kKeepEnc) make_pe(true);
     stage8(IPE{}, IH{}, IPE{}, IH{}, &pe[0][0], &hA[0][0], &hB[0][0], bias_off_stage(5), true, pre_of(4, &hA[0][0]));
     keep_masks();
     stage8(I0{}, IH{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], bias_off_stage(6), true, pre_of(5, &hB[0][0]));
@@ -268,6 +289,7 @@ __global__ __launch_bounds__(64 * Prec<P>::WAVES) void mlp_fwd_kernel(FwdArgs a)
       Frag* feat = nxt;
       Frag* h9 = cur;
       clear_masks();
+      if (!kKeepEnc) make_dir(true);
       pipe.template run_tiles<KS_H, KS_DIR, 4, NJ, KS_H, KS_DIRA>(
           feat, &dir[0][0], [&](int nt) { return bias_tile(bias_lds, kBiasViews + 32 * nt, g); },
           [&](int nt, int jt, f32x16 acc) {
@@ -373,7 +395,7 @@ extern "C" int snr_mlp_pack(const snr_mlp_config* c, const float* params, void* 
 
 template <int P, bool VD, bool TRAIN>
 static int launch_fwd(const FwdArgs& a, hipStream_t s) {
-  constexpr int per_wg = Prec<P>::WAVES * ChainNJ<P, TRAIN>::value;
+  constexpr int per_wg = ChainCfg<P, TRAIN>::WAVES * ChainCfg<P, TRAIN>::NJ;
   const int64_t n_wg = (padded_tiles<P>(a.n_samples) + per_wg - 1) / per_wg;
   const int lds = kBiasLdsBytes + kRingBytes;
   static bool attr_set = false;
@@ -386,7 +408,7 @@ static int launch_fwd(const FwdArgs& a, hipStream_t s) {
   const int64_t grid = n_wg < 1024 ? n_wg : 1024;  // one workgroup per CU is resident; the rest grid-stride
   {
     ProfScope ps(K_MLP_FWD, s);
-    mlp_fwd_kernel<P, VD, TRAIN><<<dim3((unsigned)grid), dim3(64 * Prec<P>::WAVES), lds, s>>>(a);
+    mlp_fwd_kernel<P, VD, TRAIN><<<dim3((unsigned)grid), dim3(64 * ChainCfg<P, TRAIN>::WAVES), lds, s>>>(a);
   }
   return launch_status();
 }

@@ -42,21 +42,25 @@ constexpr int kTileSamples = 32;
 enum Precision { kBF16 = 0, kFP32 = 1 };
 
 template <int P> struct Prec;
-// WAVES = waves per workgroup of the chained kernels (forward, dgrad): one per SIMD, each with the
-// whole 512-entry VGPR+AGPR file.  NJ = 32-sample tiles per wave: with two tiles every weight
-// fragment read from LDS feeds two MFMAs — measured on MI355X, re-reading all 16 fragments of a 16 KiB
-// block from every wave costs ~1040 cycles per block against 512 cycles of MFMA at NJ = 1, i.e. LDS read
-// traffic, not the matrix pipe, paces the chain.  fp32 activations of one tile already take 256
-// registers, so the parity path stays at one tile per wave.
-template <> struct Prec<kBF16> { static constexpr int EPF = 8, FPT = 2, ESZ = 2, WAVES = 4, NJ = 2; };
-template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4, WAVES = 4, NJ = 1; };
-// The training kernels (forward with saved activations, dgrad) run one tile per wave for now: their
-// activation stores share the vmcnt counter with the DMA stream, and at two tiles per wave the
-// conservative counted wait stalls on them (measured: forward 0.39 vs 0.37 ms, dgrad spills).
-template <int P, bool TRAIN> struct ChainNJ { static constexpr int value = TRAIN ? 1 : Prec<P>::NJ; };
+template <> struct Prec<kBF16> { static constexpr int EPF = 8, FPT = 2, ESZ = 2; };
+template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4; };
+
+// Shape of a chained-kernel workgroup (forward, dgrad): WAVES waves, each owning NJ tiles of 32 samples.
+// Measured on MI355X (196 608 samples, bf16 forward): every LDS-DMA instruction blocks its issuing
+// wave ~170 cycles and a wave re-reads all 16 weight fragments of each block, so with one wave per SIMD
+// the matrix pipe idles during both.
+//  * inference forward, bf16: 8 waves = two per SIMD (a wave stuck in DMA issue or an epilogue is
+//    covered by its SIMD partner); needs <= 256 registers per wave, which fits once the encodings are
+//    re-derived where consumed instead of kept (1044 TFLOP/s vs 965 at 4 waves x 2 tiles, 817 at 4 x 1);
+//  * training forward and dgrad, bf16: 4 waves x 1 tile — with saved-activation stores and masks they
+//    spill at 256 registers (measured 47 / 76 dwords, slower), and at 2 tiles per wave the stores stall
+//    the counted DMA wait;
+//  * fp32 (parity path): 4 waves x 1 tile — its activations alone are 256 registers.
+template <int P, bool TRAIN> struct ChainCfg { static constexpr int WAVES = 4, NJ = 1; };
+template <> struct ChainCfg<kBF16, false> { static constexpr int WAVES = 8, NJ = 1; };
 // 32-sample tiles of the saved-activation sections: padded to whole training workgroups
 template <int P> SNR_HD int64_t padded_tiles(int64_t n_samples) {
-  constexpr int per_wg = Prec<P>::WAVES;
+  constexpr int per_wg = ChainCfg<P, true>::WAVES * ChainCfg<P, true>::NJ;
   constexpr int wg = kTileSamples * per_wg;
   return (n_samples + wg - 1) / wg * per_wg;
 }
