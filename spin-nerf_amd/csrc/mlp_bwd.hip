@@ -78,7 +78,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
 #pragma unroll
         for (int f = 0; f < n; ++f)
           if (f >= n * nt / NT && f < n * (nt + 1) / NT)
-            *(Frag*)(base + f * 1024 + act_row<P>(sj, f) * 32) = src[jt * stride + f];
+            __builtin_nontemporal_store(src[jt * stride + f], (Frag*)(base + f * 1024 + act_row<P>(sj, f) * 32));
       }
     };
     auto mask_load = [&](int64_t sec_off, u32x4* mk) {

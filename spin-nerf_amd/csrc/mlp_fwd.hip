@@ -189,7 +189,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
 #pragma unroll
         for (int f = 0; f < n; ++f)
           if (f >= n * nt / NT && f < n * (nt + 1) / NT)
-            *(Frag*)(base + f * 1024 + act_row<P>(sj, f) * 32) = src[jt * stride + f];
+            __builtin_nontemporal_store(src[jt * stride + f], (Frag*)(base + f * 1024 + act_row<P>(sj, f) * 32));
       }
     };
     using I4 = std::integral_constant<int, 4>;

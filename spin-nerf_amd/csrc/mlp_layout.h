@@ -58,6 +58,9 @@ template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4;
 //  * fp32 (parity path): 4 waves x 1 tile — its activations alone are 256 registers.
 template <int P, bool TRAIN> struct ChainCfg { static constexpr int WAVES = 4, NJ = 1; };
 template <> struct ChainCfg<kBF16, false> { static constexpr int WAVES = 8, NJ = 1; };
+#ifdef SNR_TRAIN_WAVES8   // experiment: training kernels at two waves per SIMD too
+template <> struct ChainCfg<kBF16, true> { static constexpr int WAVES = 8, NJ = 1; };
+#endif
 // 32-sample tiles of the saved-activation sections: padded to whole training workgroups
 template <int P> SNR_HD int64_t padded_tiles(int64_t n_samples) {
   constexpr int per_wg = ChainCfg<P, true>::WAVES * ChainCfg<P, true>::NJ;
