@@ -52,15 +52,15 @@ template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4;
 //  * inference forward, bf16: 8 waves = two per SIMD (a wave stuck in DMA issue or an epilogue is
 //    covered by its SIMD partner); needs <= 256 registers per wave, which fits once the encodings are
 //    re-derived where consumed instead of kept (1044 TFLOP/s vs 965 at 4 waves x 2 tiles, 817 at 4 x 1);
-//  * training forward and dgrad, bf16: 4 waves x 1 tile — with saved-activation stores and masks they
-//    spill at 256 registers (measured 47 / 76 dwords, slower), and at 2 tiles per wave the stores stall
-//    the counted DMA wait;
+//  * training forward and dgrad, bf16: 4 waves x 2 tiles — with saved-activation stores and masks they
+//    spill at 256 registers (measured 47 / 76 dwords, slower), so they stay at one wave per SIMD and
+//    instead let every weight fragment feed two MFMAs;
 //  * fp32 (parity path): 4 waves x 1 tile — its activations alone are 256 registers.
 template <int P, bool TRAIN> struct ChainCfg { static constexpr int WAVES = 4, NJ = 1; };
 template <> struct ChainCfg<kBF16, false> { static constexpr int WAVES = 8, NJ = 1; };
-#ifdef SNR_TRAIN_WAVES8   // experiment: training kernels at two waves per SIMD too
-template <> struct ChainCfg<kBF16, true> { static constexpr int WAVES = 8, NJ = 1; };
-#endif
+// training forward / dgrad, bf16: A/B on MI355X (196 608 samples, non-temporal activation stores):
+// 4 waves x 2 tiles = 0.373 / 0.286 ms vs 4 x 1 = 0.384 / 0.331 ms; 8 waves x 1 spills and is slower.
+template <> struct ChainCfg<kBF16, true> { static constexpr int WAVES = 4, NJ = 2; };
 // 32-sample tiles of the saved-activation sections: padded to whole training workgroups
 template <int P> SNR_HD int64_t padded_tiles(int64_t n_samples) {
   constexpr int per_wg = ChainCfg<P, true>::WAVES * ChainCfg<P, true>::NJ;
