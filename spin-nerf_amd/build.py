@@ -15,9 +15,12 @@ LIB_PATH = os.path.join(LIB_DIR, "libspinnerf_hip.so")
 
 # (source, extra flags).  render_ops is built without FMA contraction so its elementwise fp32
 # arithmetic rounds like the reference's separate torch ops.
+# The two fused-MLP sources also keep their gfx950 listing (lib/<name>.gfx950.s): their LDS reads are inline
+# asm with hand-counted waits, and tools/check_lds_asm.py verifies on the listing that nothing touches a
+# destination register before its wait — build() fails if it does.
 SOURCES = [
-    ("mlp_fwd.hip", []),
-    ("mlp_bwd.hip", []),
+    ("mlp_fwd.hip", ["-save-temps=obj"]),
+    ("mlp_bwd.hip", ["-save-temps=obj"]),
     ("render_ops.hip", ["-ffp-contract=off"]),
     ("prof.cpp", ["-x", "hip"]),
 ]
@@ -36,6 +39,25 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _keep_listings(verbose):
+    """-save-temps leaves a dozen intermediates per source in lib/: keep the device listing, drop the rest,
+    and run the LDS-wait checker on every listing."""
+    for f in os.listdir(LIB_DIR):
+        p = os.path.join(LIB_DIR, f)
+        if f.endswith("-hip-amdgcn-amd-amdhsa-gfx950.s"):
+            os.replace(p, os.path.join(LIB_DIR, f.split("-hip-")[0] + ".gfx950.s"))
+        elif "-hip-amdgcn-amd-amdhsa" in f or "-host-x86_64" in f or f.endswith(".hipfb"):
+            os.remove(p)
+    listings = sorted(os.path.join(LIB_DIR, f) for f in os.listdir(LIB_DIR) if f.endswith(".gfx950.s"))
+    if listings:
+        tool = os.path.join(os.path.dirname(HERE), "tools", "check_lds_asm.py")
+        r = subprocess.run([sys.executable, tool] + listings, capture_output=True, text=True)
+        if verbose or r.returncode:
+            print(r.stdout.strip()[-2000:], flush=True)
+        if r.returncode:
+            raise RuntimeError("check_lds_asm.py: an asm LDS read is consumed before its wait")
 
 
 def build(force=False, verbose=True):
@@ -58,6 +80,7 @@ def build(force=False, verbose=True):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    _keep_listings(verbose)
     if force or procs or _stale(LIB_PATH, objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:

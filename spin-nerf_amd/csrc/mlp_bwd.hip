@@ -70,20 +70,28 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
     const int64_t tile0 = (wg * WAVES + wave) * NJ;
 
     // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section for every sample tile of this wave
-    auto ws_store = [&](int64_t sec_off, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
+    // (uniform base) + (lane offset) addressing, section bases derived at the point of use: mlp_fwd.hip
+    const uint32_t lane_even = g * 16 + sj * 32, lane_odd = g * 16 + act_row<P>(sj, 1) * 32;
+    auto ws_store = [&](int k_sec, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
       constexpr int n = decltype(N_)::value, stride = decltype(STRIDE_)::value, NT = decltype(NT_)::value;
 #pragma unroll
       for (int jt = 0; jt < NJ; ++jt) {
-        char* base = a.ws + sec_off + ((tile0 + jt) * n) * 1024 + g * 16;
+        int64_t tl = WL.n_tiles;
+        asm volatile("" : "+s"(tl));
+        char* base = a.ws + (tl * k_sec + (tile0 + jt) * n) * 1024;
 #pragma unroll
         for (int f = 0; f < n; ++f)
           if (f >= n * nt / NT && f < n * (nt + 1) / NT)
-            __builtin_nontemporal_store(src[jt * stride + f], (Frag*)(base + f * 1024 + act_row<P>(sj, f) * 32));
+            __builtin_nontemporal_store(src[jt * stride + f], (Frag*)(base + f * 1024 + (size_t)((f & 1) ? lane_odd : lane_even)));
       }
     };
-    auto mask_load = [&](int64_t sec_off, u32x4* mk) {
+    auto mask_load = [&](int k_sec, u32x4* mk) {
 #pragma unroll
-      for (int jt = 0; jt < NJ; ++jt) mk[jt] = *(const u32x4*)(a.act + sec_off + (tile0 + jt) * 1024 + lane * 16);
+      for (int jt = 0; jt < NJ; ++jt) {
+        int64_t tl = AL.n_tiles;
+        asm volatile("" : "+s"(tl));
+        mk[jt] = *(const u32x4*)(a.act + (tl * k_sec + tile0 + jt) * 1024 + (size_t)(lane * 16u));
+      }
     };
 
     // ---- d raw -> OUT frag (bf16: k-slot 8g+e = channel; fp32: k-slot g of step e = channel 2e+g)
@@ -117,54 +125,59 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
       pipe.template run_tiles<KA, KB, NT, NJ, SA, SB>(
           sa, sb, [&](int) { return zero16; },
           [&](int nt, int jt, f32x16 acc) {
-            if (use_mask) {
-              const unsigned bits = mk_cur[jt][nt >> 1] >> (16 * (nt & 1));
+            Frag* out = dst + jt * KS_H + nt * FPT;
+            if constexpr (P == kBF16) {   // flag layout: mlp_device.h
+              finish_dgrad_bf16(acc, out, use_mask, mk_cur[jt][nt >> 1], 8 * (nt & 1));
+            } else {
+              if (use_mask) {
+                const unsigned bits = mk_cur[jt][nt >> 1] >> (16 * (nt & 1));
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[r] = ((bits >> r) & 1u) ? acc[r] : 0.f;
+                for (int r = 0; r < 16; ++r) acc[r] = ((bits >> r) & 1u) ? acc[r] : 0.f;
+              }
+              acc_to_frags<P>(acc, out);
             }
-            acc_to_frags<P>(acc, dst + jt * KS_H + nt * FPT);
           },
           pre);
     };
 
     if constexpr (VD) {
-      mask_load(AL.off_mask9(), mk_cur);
-      mask_load(AL.off_mask(7), mk_next);
+      mask_load(AL.k_mask9(), mk_cur);
+      mask_load(AL.k_mask(7), mk_next);
       // d z9 = relu'(h9) * (W_rgb^T d rgb)                 -> hB[.][0..KS_H9)
       stage(I1{}, I0{}, I4{}, I1{}, I1{}, &dout[0], &dout[0], &hB[0][0], true,
-            [&](int nt) { ws_store(WL.off_dout(), I1{}, &dout[0], I1{}, nt, I4{}); });
+            [&](int nt) { ws_store(WL.k_dout(), I1{}, &dout[0], I1{}, nt, I4{}); });
       // d feat = W_views[:, :256]^T d z9                    -> hA
       stage(IH9{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], false,
-            [&](int nt) { ws_store(WL.off_dz9(), IH9{}, &hB[0][0], IH{}, nt, I8{}); });
+            [&](int nt) { ws_store(WL.k_dz9(), IH9{}, &hB[0][0], IH{}, nt, I8{}); });
       // d z7 = relu'(h7) * (W_feat^T d feat + W_alpha^T d alpha) -> hB
       roll_masks();
-      mask_load(AL.off_mask(6), mk_next);
+      mask_load(AL.k_mask(6), mk_next);
       stage(IH{}, I1{}, I8{}, IH{}, I1{}, &hA[0][0], &dout[0], &hB[0][0], true,
-            [&](int nt) { ws_store(WL.off_dfeat(), IH{}, &hA[0][0], IH{}, nt, I8{}); });
+            [&](int nt) { ws_store(WL.k_dfeat(), IH{}, &hA[0][0], IH{}, nt, I8{}); });
     } else {
-      mask_load(AL.off_mask(7), mk_cur);
-      mask_load(AL.off_mask(6), mk_next);
+      mask_load(AL.k_mask(7), mk_cur);
+      mask_load(AL.k_mask(6), mk_next);
       // d z7 = relu'(h7) * (W_out^T d raw)                  -> hB
       stage(I1{}, I0{}, I8{}, I1{}, I1{}, &dout[0], &dout[0], &hB[0][0], true,
-            [&](int nt) { ws_store(WL.off_dout(), I1{}, &dout[0], I1{}, nt, I8{}); });
+            [&](int nt) { ws_store(WL.k_dout(), I1{}, &dout[0], I1{}, nt, I8{}); });
     }
     // d z_{i-1} = relu'(h_{i-1}) * (W_i^T d z_i), i = 7..1 ; d z7 is in hB
     for (int it = 0; it < 3; ++it) {
       const int i = 7 - 2 * it;  // consumes d z_i from hB
       roll_masks();
-      mask_load(AL.off_mask(i - 2), mk_next);
+      mask_load(AL.k_mask(i - 2), mk_next);
       stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], true,
-            [&](int nt) { ws_store(WL.off_dz(i), IH{}, &hB[0][0], IH{}, nt, I8{}); });
+            [&](int nt) { ws_store(WL.k_dz(i), IH{}, &hB[0][0], IH{}, nt, I8{}); });
       roll_masks();
-      mask_load(AL.off_mask(i - 3 >= 0 ? i - 3 : 0), mk_next);
+      mask_load(AL.k_mask(i - 3 >= 0 ? i - 3 : 0), mk_next);
       stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], true,
-            [&](int nt) { ws_store(WL.off_dz(i - 1), IH{}, &hA[0][0], IH{}, nt, I8{}); });
+            [&](int nt) { ws_store(WL.k_dz(i - 1), IH{}, &hA[0][0], IH{}, nt, I8{}); });
     }
     // i = 1: d z0 from d z1 (hB) -> hA
     roll_masks();
     stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], true,
-          [&](int nt) { ws_store(WL.off_dz(1), IH{}, &hB[0][0], IH{}, nt, I8{}); });
-    ws_store(WL.off_dz(0), IH{}, &hA[0][0], IH{}, 0, I1{});
+          [&](int nt) { ws_store(WL.k_dz(1), IH{}, &hB[0][0], IH{}, nt, I8{}); });
+    ws_store(WL.k_dz(0), IH{}, &hA[0][0], IH{}, 0, I1{});
   }
   pipe.drain();
 }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     // Encodings.  With two waves per SIMD (256 registers each) they are not kept across the trunk:
     // bf16 re-derives them where they are consumed (hardware sin/cos, ~200 instructions) — `fresh`
     // hides the inputs from common-subexpression elimination so the first copy really dies.
-    constexpr bool kKeepEnc = WAVES == 4;
+    constexpr bool kKeepEnc = P == kFP32;
     Frag pe[NJ][KS_PE];
     Frag dir[NJ][KS_DIRA];
     auto make_pe = [&](bool fresh) {
@@ -181,37 +181,55 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
 
     // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section, for every sample tile of this wave: output tile
     // nt's share of the deferred stores.  Section layout [tile][frag][32 samples][32 B].
-    auto act_store = [&](int64_t sec_off, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
+    // Addresses are (wave-uniform 64-bit base) + (32-bit lane offset): one SGPR pair and no vector address
+    // arithmetic per store.
+    const uint32_t lane_even = g * 16 + sj * 32, lane_odd = g * 16 + act_row<P>(sj, 1) * 32;
+    auto sec_base = [&](int k_sec, int64_t tile, int n) {
+      return a.act + (AL.n_tiles * k_sec + tile * n) * 1024;
+    };
+    auto act_store = [&](int k_sec, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
       constexpr int n = decltype(N_)::value, stride = decltype(STRIDE_)::value, NT = decltype(NT_)::value;
 #pragma unroll
       for (int jt = 0; jt < NJ; ++jt) {
-        char* base = a.act + sec_off + ((tile0 + jt) * n) * 1024 + g * 16;
+        char* base = sec_base(k_sec, tile0 + jt, n);
 #pragma unroll
         for (int f = 0; f < n; ++f)
           if (f >= n * nt / NT && f < n * (nt + 1) / NT)
-            __builtin_nontemporal_store(src[jt * stride + f], (Frag*)(base + f * 1024 + act_row<P>(sj, f) * 32));
+            __builtin_nontemporal_store(src[jt * stride + f], (Frag*)(base + f * 1024 + (size_t)((f & 1) ? lane_odd : lane_even)));
       }
     };
     using I4 = std::integral_constant<int, 4>;
     using I8 = std::integral_constant<int, 8>;
     using I9 = std::integral_constant<int, 9>;
     using IH9 = std::integral_constant<int, KS_H9>;
-    auto mask_store = [&](int64_t sec_off, const u32x4* mk) {
+    auto mask_store = [&](int k_sec, const u32x4* mk) {
 #pragma unroll
-      for (int jt = 0; jt < NJ; ++jt) *(u32x4*)(a.act + sec_off + (tile0 + jt) * 1024 + lane * 16) = mk[jt];
+      for (int jt = 0; jt < NJ; ++jt) *(u32x4*)(sec_base(k_sec, tile0 + jt, 1) + (size_t)(lane * 16u)) = mk[jt];
     };
 
     Frag hA[NJ][KS_H], hB[NJ][KS_H];
     u32x4 mask[NJ];
 
-    auto relu_mask = [&](int nt, int jt, f32x16& acc) {
-      unsigned bits = 0;
+    // epilogue of one output tile: [relu] -> frags, flags of the positive outputs into mask[jt]
+    // (bf16: packed, mlp_device.h; fp32: bit r of the tile's 16-bit field = C register r)
+    auto tile_out = [&](auto RELU_, int nt, int jt, f32x16 acc, Frag* dst) {
+      constexpr bool RELU = decltype(RELU_)::value;
+      if constexpr (P == kBF16) {
+        unsigned word = 0;
+        finish_fwd_bf16<RELU, RELU && TRAIN>(acc, dst, word, 8 * (nt & 1));
+        if constexpr (RELU && TRAIN) mask[jt][nt >> 1] |= word;
+      } else {
+        if constexpr (RELU) {
+          unsigned bits = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        bits |= (acc[r] > 0.f ? 1u : 0u) << r;
-        acc[r] = fmaxf(acc[r], 0.f);
+          for (int r = 0; r < 16; ++r) {
+            bits |= (acc[r] > 0.f ? 1u : 0u) << r;
+            acc[r] = fmaxf(acc[r], 0.f);
+          }
+          if constexpr (TRAIN) mask[jt][nt >> 1] |= bits << (16 * (nt & 1));
+        }
+        acc_to_frags<P>(acc, dst);
       }
-      if constexpr (TRAIN) mask[jt][nt >> 1] |= bits << (16 * (nt & 1));
     };
     auto clear_masks = [&]() {
 #pragma unroll
@@ -219,24 +237,21 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     };
     // ---- generic 8-tile stage: dst = [relu](W [sa|sb] + b); sources / dst have per-sample-tile strides ----
     auto stage8 = [&](auto KA_, auto KB_, auto SA_, auto SB_, const Frag* sa, const Frag* sb, Frag* dst, int bias_off,
-                      bool relu, auto&& pre) {
+                      auto&& pre) {
       constexpr int KA = decltype(KA_)::value, KB = decltype(KB_)::value;
       constexpr int SA = decltype(SA_)::value, SB = decltype(SB_)::value;
       clear_masks();
       pipe.template run_tiles<KA, KB, 8, NJ, SA, SB>(
-          sa, sb, [&](int nt) { return bias_tile(bias_lds, bias_off + 32 * nt, g); },
-          [&](int nt, int jt, f32x16 acc) {
-            if (relu) relu_mask(nt, jt, acc);
-            acc_to_frags<P>(acc, dst + jt * KS_H + nt * FPT);
-          },
+          sa, sb, [&](int nt) { return bias_tile_addr(bias_lds, bias_off + 32 * nt, g); },
+          [&](int nt, int jt, f32x16 acc) { tile_out(std::true_type{}, nt, jt, acc, dst + jt * KS_H + nt * FPT); },
           pre);
     };
 
     // stage 0: PE -> hA
-    stage8(IPE{}, I0{}, IPE{}, IPE{}, &pe[0][0], &pe[0][0], &hA[0][0], bias_off_stage(0), true, [&](int nt) {
+    stage8(IPE{}, I0{}, IPE{}, IPE{}, &pe[0][0], &pe[0][0], &hA[0][0], bias_off_stage(0), [&](int nt) {
       if constexpr (TRAIN) {
-        act_store(AL.off_pe(), IPE{}, &pe[0][0], IPE{}, nt, I8{});
-        if constexpr (VD) act_store(AL.off_dir(), IDIR{}, &dir[0][0], IDIRA{}, nt, I8{});
+        act_store(AL.k_pe(), IPE{}, &pe[0][0], IPE{}, nt, I8{});
+        if constexpr (VD) act_store(AL.k_dir(), IDIR{}, &dir[0][0], IDIRA{}, nt, I8{});
       }
     });
     // stages 1..7 ping-pong hA/hB; stage 5 prepends the encoding (skip connection, helpers:110-111)
@@ -248,25 +263,25 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     auto pre_of = [&](int s_prev, const Frag* src) {
       return [&, s_prev, src](int nt) {
         if constexpr (TRAIN) {
-          act_store(AL.off_h(s_prev), IH{}, src, IH{}, nt, I8{});
-          if (nt == 0) mask_store(AL.off_mask(s_prev), pmask);
+          act_store(AL.k_h(s_prev), IH{}, src, IH{}, nt, I8{});
+          if (nt == 0) mask_store(AL.k_mask(s_prev), pmask);
         }
       };
     };
     for (int it = 0; it < 2; ++it) {  // stages (1,2), (3,4)
       const int s1 = 1 + 2 * it;
       keep_masks();
-      stage8(I0{}, IH{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], bias_off_stage(s1), true, pre_of(s1 - 1, &hA[0][0]));
+      stage8(I0{}, IH{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], bias_off_stage(s1), pre_of(s1 - 1, &hA[0][0]));
       keep_masks();
-      stage8(I0{}, IH{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], bias_off_stage(s1 + 1), true, pre_of(s1, &hB[0][0]));
+      stage8(I0{}, IH{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], bias_off_stage(s1 + 1), pre_of(s1, &hB[0][0]));
     }
     keep_masks();
     if (!kKeepEnc) make_pe(true);
-    stage8(IPE{}, IH{}, IPE{}, IH{}, &pe[0][0], &hA[0][0], &hB[0][0], bias_off_stage(5), true, pre_of(4, &hA[0][0]));
+    stage8(IPE{}, IH{}, IPE{}, IH{}, &pe[0][0], &hA[0][0], &hB[0][0], bias_off_stage(5), pre_of(4, &hA[0][0]));
     keep_masks();
-    stage8(I0{}, IH{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], bias_off_stage(6), true, pre_of(5, &hB[0][0]));
+    stage8(I0{}, IH{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], bias_off_stage(6), pre_of(5, &hB[0][0]));
     keep_masks();
-    stage8(I0{}, IH{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], bias_off_stage(7), true, pre_of(6, &hA[0][0]));
+    stage8(I0{}, IH{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], bias_off_stage(7), pre_of(6, &hA[0][0]));
     keep_masks();   // masks of stage 7
     Frag* cur = &hB[0][0];   // h7
     Frag* nxt = &hA[0][0];
@@ -274,15 +289,15 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
       // stage 8: feature (8 tiles, no relu) + the alpha tile (row 0 = alpha_linear)
       float alpha[NJ];
       pipe.template run_tiles<0, KS_H, 9, NJ, KS_H, KS_H>(
-          cur, cur, [&](int nt) { return bias_tile(bias_lds, kBiasFeat + 32 * nt, g); },
+          cur, cur, [&](int nt) { return bias_tile_addr(bias_lds, kBiasFeat + 32 * nt, g); },
           [&](int nt, int jt, f32x16 acc) {
-            if (nt < 8) acc_to_frags<P>(acc, nxt + jt * KS_H + nt * FPT);
+            if (nt < 8) tile_out(std::false_type{}, nt, jt, acc, nxt + jt * KS_H + nt * FPT);
             else alpha[jt] = acc[0];  // row 0 lives in register 0 of lanes 0..31
           },
           [&](int nt) {
             if constexpr (TRAIN) {
-              act_store(AL.off_h(7), IH{}, cur, IH{}, nt, I9{});
-              if (nt == 0) mask_store(AL.off_mask(7), pmask);
+              act_store(AL.k_h(7), IH{}, cur, IH{}, nt, I9{});
+              if (nt == 0) mask_store(AL.k_mask(7), pmask);
             }
           });
       // stage 9: views = relu(W [feat | dir] + b), 4 tiles -> h9 (in `cur` storage)
@@ -291,22 +306,19 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
       clear_masks();
       if (!kKeepEnc) make_dir(true);
       pipe.template run_tiles<KS_H, KS_DIR, 4, NJ, KS_H, KS_DIRA>(
-          feat, &dir[0][0], [&](int nt) { return bias_tile(bias_lds, kBiasViews + 32 * nt, g); },
-          [&](int nt, int jt, f32x16 acc) {
-            relu_mask(nt, jt, acc);
-            acc_to_frags<P>(acc, h9 + jt * KS_H + nt * FPT);
-          },
+          feat, &dir[0][0], [&](int nt) { return bias_tile_addr(bias_lds, kBiasViews + 32 * nt, g); },
+          [&](int nt, int jt, f32x16 acc) { tile_out(std::true_type{}, nt, jt, acc, h9 + jt * KS_H + nt * FPT); },
           [&](int nt) {
-            if constexpr (TRAIN) act_store(AL.off_feat(), IH{}, feat, IH{}, nt, I4{});
+            if constexpr (TRAIN) act_store(AL.k_feat(), IH{}, feat, IH{}, nt, I4{});
           });
       // stage 10: rgb
       keep_masks();
       f32x16 acc_c[NJ];
       pipe.template run_tiles<0, KS_H9, 1, NJ, KS_H, KS_H>(
-          h9, h9, [&](int) { return bias_tile(bias_lds, kBiasRgb, g); },
+          h9, h9, [&](int) { return bias_tile_addr(bias_lds, kBiasRgb, g); },
           [&](int, int jt, f32x16 acc) { acc_c[jt] = acc; },
           [&](int) {
-            if constexpr (TRAIN) { act_store(AL.off_h9(), IH9{}, h9, IH{}, 0, I1{}); mask_store(AL.off_mask9(), pmask); }
+            if constexpr (TRAIN) { act_store(AL.k_h9(), IH9{}, h9, IH{}, 0, I1{}); mask_store(AL.k_mask9(), pmask); }
           });
 #pragma unroll
       for (int jt = 0; jt < NJ; ++jt)
@@ -314,10 +326,10 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     } else {
       f32x16 acc_o[NJ];
       pipe.template run_tiles<0, KS_H, 1, NJ, KS_H, KS_H>(
-          cur, cur, [&](int) { return bias_tile(bias_lds, kBiasOut, g); },
+          cur, cur, [&](int) { return bias_tile_addr(bias_lds, kBiasOut, g); },
           [&](int, int jt, f32x16 acc) { acc_o[jt] = acc; },
           [&](int) {
-            if constexpr (TRAIN) { act_store(AL.off_h(7), IH{}, cur, IH{}, 0, I1{}); mask_store(AL.off_mask(7), pmask); }
+            if constexpr (TRAIN) { act_store(AL.k_h(7), IH{}, cur, IH{}, 0, I1{}); mask_store(AL.k_mask(7), pmask); }
           });
       // rows 0..3 = registers 0..3 of lane half 0; row 4 = register 0 of lane half 1
 #pragma unroll

@@ -60,7 +60,11 @@ template <int P, bool TRAIN> struct ChainCfg { static constexpr int WAVES = 4, N
 template <> struct ChainCfg<kBF16, false> { static constexpr int WAVES = 8, NJ = 1; };
 // training forward / dgrad, bf16: A/B on MI355X (196 608 samples, non-temporal activation stores):
 // 4 waves x 2 tiles = 0.373 / 0.286 ms vs 4 x 1 = 0.384 / 0.331 ms; 8 waves x 1 spills and is slower.
-template <> struct ChainCfg<kBF16, true> { static constexpr int WAVES = 4, NJ = 2; };
+#if defined(SNR_TRAIN_WAVES) && defined(SNR_TRAIN_NJ)   // A/B builds only
+template <> struct ChainCfg<kBF16, true> { static constexpr int WAVES = SNR_TRAIN_WAVES, NJ = SNR_TRAIN_NJ; };
+#else
+template <> struct ChainCfg<kBF16, true> { static constexpr int WAVES = 8, NJ = 1; };
+#endif
 // 32-sample tiles of the saved-activation sections: padded to whole training workgroups
 template <int P> SNR_HD int64_t padded_tiles(int64_t n_samples) {
   constexpr int per_wg = ChainCfg<P, true>::WAVES * ChainCfg<P, true>::NJ;

@@ -15,10 +15,14 @@ template <int P> struct WsLayout {
   int64_t n_tiles;
   int vd;
   SNR_HD WsLayout(int64_t n_samples, int vd_) : n_tiles(padded_tiles<P>(n_samples)), vd(vd_) {}
+  SNR_HD int k_dout() const { return 0; }
+  SNR_HD int k_dz(int i) const { return 1 + i * B::KS_H; }  // i in 0..7
+  SNR_HD int k_dfeat() const { return 1 + 8 * B::KS_H; }
+  SNR_HD int k_dz9() const { return k_dfeat() + B::KS_H; }
   SNR_HD int64_t off_dout() const { return 0; }
-  SNR_HD int64_t off_dz(int i) const { return n_tiles * 1024 * (1 + (int64_t)i * B::KS_H); }  // i in 0..7
-  SNR_HD int64_t off_dfeat() const { return n_tiles * 1024 * (1 + 8 * (int64_t)B::KS_H); }
-  SNR_HD int64_t off_dz9() const { return off_dfeat() + n_tiles * 1024 * B::KS_H; }
+  SNR_HD int64_t off_dz(int i) const { return n_tiles * 1024 * k_dz(i); }
+  SNR_HD int64_t off_dfeat() const { return n_tiles * 1024 * k_dfeat(); }
+  SNR_HD int64_t off_dz9() const { return n_tiles * 1024 * k_dz9(); }
   SNR_HD int64_t dz_bytes() const {
     return n_tiles * 1024 * (1 + 8 * (int64_t)B::KS_H + (vd ? B::KS_H + B::KS_H9 : 0));
   }
@@ -87,6 +91,17 @@ constexpr int kWgradWaves = 8;
 // Everything that does not change from tile to tile (DMA source pointers, LDS offsets of the
 // transposing reads) is computed once up front; the per-tile loop is waits, 2*NI... DMA issues,
 // ds_read_b64_tr_b16 with immediate offsets, and MFMAs.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <int OFF> __device__ __forceinline__ void tr_read(bf16x4& dst, uint32_t addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void tr_wait(bf16x4& a, bf16x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N < 15 ? N : 15));
+}
+template <int N> __device__ __forceinline__ void tr_wait(bf16x4& a, bf16x4& b, bf16x4& c, bf16x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N < 15 ? N : 15));
+}
+
 template <int P, int NTB, int NX, int NI>
 __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int wave, int lane, int ta0, int ni) {
   using M = Mma<P>;
@@ -115,7 +130,11 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
     if (k < ni) __builtin_amdgcn_global_load_lds(src[k], SNR_LDS(smem + slot * SLOT + lds_off[k]), 16, 0, SNR_WGRAD_AUX);
   };
   auto advance = [&]() {   // past the end the last tile is re-loaded: the instruction count stays uniform
+#if defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 4   // timing experiment: the stream re-reads one tile (L2 hits)
+    if (false) {
+#else
     if (src_tile + 1 < L.t1) {
+#endif
       ++src_tile;
 #pragma unroll
       for (int k = 0; k < NI; ++k) src[k] += stride[k];
@@ -169,36 +188,40 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
     if constexpr (NX > 0) {
       char* sbase = smem + slot * SLOT;
       if constexpr (P == kBF16) {
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) bf16x4* lds_b4;
-        char* pa0 = sbase + offA[0];
-        char* pa1 = sbase + offA[1];
-        char* pb0 = sbase + offB[0];
-        char* pb1 = sbase + offB[1];
+        // The transposing reads are inline asm with hand-counted completion (mlp_device.h, Pipe: reads the
+        // compiler knows about are ordered behind every outstanding LDS-DMA load, i.e. vmcnt(0) per read).
+        const uint32_t sb32 = lds_addr(smem) + slot * SLOT;
+        const uint32_t aA0 = sb32 + offA[0], aA1 = sb32 + offA[1], aB0 = sb32 + offB[0], aB1 = sb32 + offB[1];
+        static_for<0, 2>([&](auto H_) {
+          constexpr int half = decltype(H_)::value;
+          bf16x4 alo, ahi, blo[NTB], bhi[NTB];
+          tr_read<half * 512>(alo, aA0);
+          tr_read<half * 512>(ahi, aA1);
+          static_for<0, NTB>([&](auto Y_) {
+            constexpr int y = decltype(Y_)::value;
+            tr_read<y * 2048 + half * 512>(blo[y], aB0);
+            tr_read<y * 2048 + half * 512>(bhi[y], aB1);
+          });
+          Frag fa;
+          static_for<0, NTB>([&](auto Y_) {
+            constexpr int y = decltype(Y_)::value;
+            // LDS reads retire in order: everything up to B pair y has landed once at most the
+            // 2*(NTB-1-y) younger reads are outstanding
+            if constexpr (y == 0) {
+              tr_wait<2 * (NTB - 1)>(alo, ahi, blo[0], bhi[0]);
+              fa = Frag{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+              if (do_bias) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          Frag fa, fb[NTB];
-          {
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pa0 + half * 512));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pa1 + half * 512));
-            fa = Frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          }
-#pragma unroll
-          for (int y = 0; y < NTB; ++y) {
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pb0 + y * 2048 + half * 512));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pb1 + y * 2048 + half * 512));
-            fb[y] = Frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          }
-          if (do_bias) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bsum += (float)fa[e];
-          }
-#pragma unroll
-          for (int y = 0; y < NTB; ++y) {
-            acc[0][y] = M::mma(fa, fb[y], acc[0][y]);
+                for (int e = 0; e < 8; ++e) bsum += (float)fa[e];
+              }
+            } else {
+              tr_wait<2 * (NTB - 1 - y)>(blo[y], bhi[y]);
+            }
+            const Frag fb = Frag{blo[y][0], blo[y][1], blo[y][2], blo[y][3], bhi[y][0], bhi[y][1], bhi[y][2], bhi[y][3]};
+            acc[0][y] = M::mma(fa, fb, acc[0][y]);
             if ((NTB < 8 || (y & 1)) && kq < NI) { SNR_WGRAD_ISSUE(kq); ++kq; }
-          }
-        }
+          });
+        });
       } else {
         // fp32: A[i = neuron][k = sample 2*ks2 + g], one float per lane; saved layout [q = neuron/8][sample][8]
         const float* fa_base = (const float*)sbase;

@@ -1,0 +1,67 @@
+"""CPU: the fused kernels read LDS through inline asm with hand-counted s_waitcnt lgkmcnt(N) (the compiler
+would otherwise drain the LDS-DMA queue in front of every read).  tools/check_lds_asm.py proves on the
+gfx950 listing that no instruction touches a destination register before a wait has covered it."""
+import importlib.util
+import os
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("check_lds_asm", os.path.join(ROOT, "tools", "check_lds_asm.py"))
+chk = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(chk)
+
+
+def _listing(tmp_path, body):
+    p = tmp_path / "k.s"
+    p.write_text("_Z6kernelv:\n" + textwrap.dedent(body) + "\ts_endpgm\n")
+    return str(p)
+
+
+def test_checker_accepts_counted_waits(tmp_path):
+    ok = """
+        ;;#ASMSTART
+        ds_read_b128 v[0:3], v9 offset:0
+        ;;#ASMEND
+        ;;#ASMSTART
+        ds_read_b128 v[4:7], v9 offset:1024
+        ;;#ASMEND
+        ;;#ASMSTART
+        s_waitcnt lgkmcnt(1)
+        ;;#ASMEND
+        v_mfma_f32_32x32x16_bf16 v[16:31], v[0:3], v[40:43], v[16:31]
+        ;;#ASMSTART
+        s_waitcnt lgkmcnt(0)
+        ;;#ASMEND
+        v_mfma_f32_32x32x16_bf16 v[16:31], v[4:7], v[40:43], v[16:31]
+    """
+    assert chk.check(_listing(tmp_path, ok)) == 0
+
+
+def test_checker_flags_early_use(tmp_path):
+    bad = """
+        ;;#ASMSTART
+        ds_read_b128 v[0:3], v9 offset:0
+        ;;#ASMEND
+        ;;#ASMSTART
+        ds_read_b128 v[4:7], v9 offset:1024
+        ;;#ASMEND
+        ;;#ASMSTART
+        s_waitcnt lgkmcnt(1)
+        ;;#ASMEND
+        v_mov_b32_e32 v20, v5
+    """
+    assert chk.check(_listing(tmp_path, bad)) == 1
+
+
+def test_built_listings_are_clean():
+    lib = os.path.join(ROOT, "spin-nerf_amd", "lib")
+    listings = [os.path.join(lib, f) for f in sorted(os.listdir(lib))] if os.path.isdir(lib) else []
+    listings = [p for p in listings if p.endswith(".gfx950.s")]
+    if not listings:
+        pytest.skip("no device listing (run __graft_entry__.build() first)")
+    for p in listings:
+        assert chk.check(p) == 0, p
+        txt = open(p).read()
+        assert "ds_read_b128" in txt   # the listing really contains the asm reads

@@ -1,0 +1,65 @@
+"""Static check of the hand-counted LDS waits in a hipcc -S listing.
+
+The fused kernels read LDS through inline asm (ds_read_b128 / ds_read_b64_tr_b16) and wait with
+asm `s_waitcnt lgkmcnt(N)`; the compiler does not know those registers are in flight.  This walks every
+kernel linearly and reports any instruction that touches the destination of an asm LDS read before a
+wait has covered it (LDS operations retire in order: a read is complete once a wait with
+N <= number of LDS reads issued after it has executed).  Branch targets are ignored (straight-line model).
+
+  python tools/check_lds_asm.py file.s   -> exit status 1 on a violation
+"""
+import re, sys
+
+REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
+
+def regs(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1):
+            out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+        else:
+            out.add((m.group(4), int(m.group(5))))
+    return out
+
+def check(path):
+    bad = 0
+    kernel, pending, issued, in_asm = None, [], 0, False
+    for ln, line in enumerate(open(path), 1):
+        s = line.strip()
+        if s.endswith(":") and s.startswith("_Z"):
+            kernel, pending, issued = s[:-1], [], 0
+            continue
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True; continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False; continue
+        if not s or s.startswith((";", ".", "//")) or kernel is None:
+            continue
+        code = s.split(";")[0]
+        if in_asm and code.startswith("ds_read"):
+            dst = regs(code.split(",")[0])
+            issued += 1
+            pending.append((issued, dst, ln))
+            continue
+        m = re.match(r"s_waitcnt\s+(.*)", code)
+        if m:
+            lg = re.search(r"lgkmcnt\((\d+)\)", m.group(1))
+            if lg:
+                n = int(lg.group(1))
+                pending = [p for p in pending if issued - p[0] < n]   # younger than the n most recent stay
+            continue
+        if code.startswith("s_endpgm"):
+            pending = []
+            continue
+        touched = regs(code)
+        for seq, dst, l0 in pending:
+            if touched & dst:
+                print(f"{path}:{ln}: {kernel[:60]}: `{code.strip()}` touches the destination of the LDS read at line {l0} before its wait")
+                bad += 1
+                break
+    return bad
+
+if __name__ == "__main__":
+    n = sum(check(p) for p in sys.argv[1:])
+    print("violations:", n)
+    sys.exit(1 if n else 0)
