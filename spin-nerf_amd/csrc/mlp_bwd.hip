@@ -78,21 +78,30 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
       for (int jt = 0; jt < NJ; ++jt) {
         int64_t tl = WL.n_tiles;
         asm volatile("" : "+s"(tl));
-        char* base = a.ws + (tl * k_sec + (tile0 + jt) * n) * 1024;
-#pragma unroll
-        for (int f = 0; f < n; ++f)
-          if (f >= n * nt / NT && f < n * (nt + 1) / NT)
-            __builtin_nontemporal_store(src[jt * stride + f], (Frag*)(base + f * 1024 + (size_t)((f & 1) ? lane_odd : lane_even)));
+        store_tile_slice<P, n, NT>(a.ws + (tl * k_sec + (tile0 + jt) * n) * 1024, src + jt * stride, nt, lane_even, lane_odd);
       }
     };
+    // ReLU flags of a stage, 16 B per lane.  Also asm (a load the compiler sees is waited for with vmcnt(0) at
+    // its first use if anything else is pending).  Completion: loads retire in order, so once at most W
+    // younger operations are outstanding and more than W DMA pieces were issued behind the load, it has
+    // landed — masks_ready<W>() says so to the compiler.  Every load below sits at least one long stage
+    // (>= 4 blocks = 8 pieces) ahead of its use, where W = 6 is what the block waits enforce anyway.
     auto mask_load = [&](int k_sec, u32x4* mk) {
 #pragma unroll
       for (int jt = 0; jt < NJ; ++jt) {
         int64_t tl = AL.n_tiles;
         asm volatile("" : "+s"(tl));
-        mk[jt] = *(const u32x4*)(a.act + (tl * k_sec + tile0 + jt) * 1024 + (size_t)(lane * 16u));
+        const char* base = a.act + (tl * k_sec + tile0 + jt) * 1024;
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(mk[jt]) : "v"(lane * 16u), "s"(base));   // s_nop: store16_stream
       }
     };
+    auto masks_ready = [&](auto W_, u32x4* mk) {
+#pragma unroll
+      for (int jt = 0; jt < NJ; ++jt) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(mk[jt]) : "n"(decltype(W_)::value));
+    };
+    using W0 = std::integral_constant<int, 0>;
+    using W1 = std::integral_constant<int, 1>;
+    using W6 = std::integral_constant<int, 6>;
 
     // ---- d raw -> OUT frag (bf16: k-slot 8g+e = channel; fp32: k-slot g of step e = channel 2e+g)
     Frag dout[NJ];
@@ -112,7 +121,8 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
 
     Frag hA[NJ][KS_H], hB[NJ][KS_H];
     u32x4 mk_cur[NJ], mk_next[NJ];
-    auto roll_masks = [&]() {
+    auto roll_masks = [&](auto W_) {
+      masks_ready(W_, mk_next);
 #pragma unroll
       for (int jt = 0; jt < NJ; ++jt) mk_cur[jt] = mk_next[jt];
     };
@@ -143,6 +153,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
     if constexpr (VD) {
       mask_load(AL.k_mask9(), mk_cur);
       mask_load(AL.k_mask(7), mk_next);
+      masks_ready(W1{}, mk_cur);   // used right away: everything but the one younger load has to be back
       // d z9 = relu'(h9) * (W_rgb^T d rgb)                 -> hB[.][0..KS_H9)
       stage(I1{}, I0{}, I4{}, I1{}, I1{}, &dout[0], &dout[0], &hB[0][0], true,
             [&](int nt) { ws_store(WL.k_dout(), I1{}, &dout[0], I1{}, nt, I4{}); });
@@ -150,31 +161,33 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
       stage(IH9{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], false,
             [&](int nt) { ws_store(WL.k_dz9(), IH9{}, &hB[0][0], IH{}, nt, I8{}); });
       // d z7 = relu'(h7) * (W_feat^T d feat + W_alpha^T d alpha) -> hB
-      roll_masks();
+      roll_masks(W6{});
       mask_load(AL.k_mask(6), mk_next);
       stage(IH{}, I1{}, I8{}, IH{}, I1{}, &hA[0][0], &dout[0], &hB[0][0], true,
             [&](int nt) { ws_store(WL.k_dfeat(), IH{}, &hA[0][0], IH{}, nt, I8{}); });
     } else {
       mask_load(AL.k_mask(7), mk_cur);
       mask_load(AL.k_mask(6), mk_next);
+      masks_ready(W1{}, mk_cur);
       // d z7 = relu'(h7) * (W_out^T d raw)                  -> hB
       stage(I1{}, I0{}, I8{}, I1{}, I1{}, &dout[0], &dout[0], &hB[0][0], true,
             [&](int nt) { ws_store(WL.k_dout(), I1{}, &dout[0], I1{}, nt, I8{}); });
+      masks_ready(W1{}, mk_next);   // only one block (2 DMA pieces) was issued behind this load so far
     }
     // d z_{i-1} = relu'(h_{i-1}) * (W_i^T d z_i), i = 7..1 ; d z7 is in hB
     for (int it = 0; it < 3; ++it) {
       const int i = 7 - 2 * it;  // consumes d z_i from hB
-      roll_masks();
+      roll_masks(W6{});
       mask_load(AL.k_mask(i - 2), mk_next);
       stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], true,
             [&](int nt) { ws_store(WL.k_dz(i), IH{}, &hB[0][0], IH{}, nt, I8{}); });
-      roll_masks();
+      roll_masks(W6{});
       mask_load(AL.k_mask(i - 3 >= 0 ? i - 3 : 0), mk_next);
       stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], true,
             [&](int nt) { ws_store(WL.k_dz(i - 1), IH{}, &hA[0][0], IH{}, nt, I8{}); });
     }
     // i = 1: d z0 from d z1 (hB) -> hA
-    roll_masks();
+    roll_masks(W6{});
     stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], true,
           [&](int nt) { ws_store(WL.k_dz(1), IH{}, &hB[0][0], IH{}, nt, I8{}); });
     ws_store(WL.k_dz(0), IH{}, &hA[0][0], IH{}, 0, I1{});

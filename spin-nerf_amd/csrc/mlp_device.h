@@ -37,6 +37,9 @@ template <int P> __device__ __forceinline__ int act_row(int j, int f) {
 //                                  previous block, so the slot of the one before it (cur-2) can be
 //                                  re-filled with block cur+kDepth while reads of cur-1 may still fly.
 // No __syncthreads(): its fence would drain the whole prefetch queue (vmcnt(0)) every time.
+#ifndef SNR_ABLATE
+#define SNR_ABLATE 0   // bit mask of timing experiments (results are garbage): see Pipe
+#endif
 constexpr int kBlockFrags = 16;
 constexpr int kRing = 6;
 constexpr int kDepth = 4;    // = kRing - 2: the slot re-filled on entering block b is that of block b-2
@@ -92,7 +95,15 @@ template <int P, int WAVES_> struct Pipe {
     issue_slot = issue_slot + 1 == kRing ? 0 : issue_slot + 1;
   }
   __device__ __forceinline__ void issue_one() {
+#if SNR_ABLATE & 8   // timing experiment: no DMA
+    pend = 0;
+#endif
     if (pend > 0) {
+      // One wait state in front of the DMA.  Measured on MI355X: with an (asm) ds_read issued in the cycle
+      // before it, the DMA occasionally went out with a corrupt global address (memory fault with the upper
+      // address half zero, ~1 launch in 2 of the fp32 kernel; never with the s_nop).  The compiler separates
+      // the two when it knows both instructions; it cannot see into the asm.
+      asm volatile("s_nop 0");
       __builtin_amdgcn_global_load_lds(pend_src + (size_t)lane_off, SNR_LDS(pend_dst), 16, 0, 0);
       pend_src += WAVES * 1024;
       pend_dst += WAVES * 1024;
@@ -104,9 +115,16 @@ template <int P, int WAVES_> struct Pipe {
   }
 
   __device__ __forceinline__ void acquire() {
+#if SNR_ABLATE & 2   // timing experiment (racy): no wait, no barrier
+    flush(); cur_slot = cur_slot + 1 == kRing ? 0 : cur_slot + 1; begin_issue(); return;
+#endif
     flush();   // the counted wait below assumes every older block is completely issued
     // allowed outstanding = this wave's pieces of the kDepth-1 younger blocks
     static_assert(PIECES * (kDepth - 1) == 6 || PIECES * (kDepth - 1) == 12, "add the immediate");
+#if SNR_ABLATE & 16   // timing experiment (racy): tolerate 24 more outstanding operations (stores)
+    if constexpr (PIECES * (kDepth - 1) == 6) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+    else
+#endif
     if constexpr (PIECES * (kDepth - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -217,7 +235,9 @@ template <int P, int WAVES_> struct Pipe {
           else acc[j] = M::mma(w[i % G], sb[j * SB + (f - KA)], acc[j]);
         }
         if constexpr (f == 0) {
+#if !(SNR_ABLATE & 4)   // timing experiment: no activation stores
           pre(nt);   // this tile's slice of the deferred global stores
+#endif
           if constexpr (OVERLAP && nt > 0) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) finish(nt - 1, j, prev[j]);
@@ -231,8 +251,13 @@ template <int P, int WAVES_> struct Pipe {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) prev[j] = acc[j];
       } else {
+#if SNR_ABLATE & 1   // timing experiment: no epilogue
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[j]));
+#else
 #pragma unroll
         for (int j = 0; j < NJ; ++j) finish(nt, j, acc[j]);
+#endif
       }
     });
     if constexpr (OVERLAP) {
@@ -264,8 +289,25 @@ __device__ __forceinline__ void acc_to_frags(const f32x16& acc, typename Mma<P>:
 //   dgrad     = v_pk_mul_lo_u16(x, flag)    (bit pattern times 0 / 1)
 // Flag layout of one 32-neuron output tile inside a 32-bit word (two tiles per word, sh = 8 * (nt & 1)):
 // packed word D = 0..7 of the tile (C registers 2D, 2D+1) -> bits D + sh and 16 + D + sh.
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// The packed instructions are inline asm: written with vector types the optimiser turns min(x, 1) into a
+// per-element compare + select and scalarises the whole epilogue (5 instructions per element, measured).
+// The conversion itself stays with the compiler — it is the first reader of the MFMA result and the
+// compiler has to see that to insert the wait states between an MFMA and a VALU read of its output.
+__device__ __forceinline__ unsigned pk_relu_bf16(unsigned x) {
+  unsigned r;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ unsigned pk_nonzero_u16(unsigned x) {   // 1 per non-zero half
+  unsigned r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "s"(0x00010001u));
+  return r;
+}
+__device__ __forceinline__ unsigned pk_mul_u16(unsigned x, unsigned y) {
+  unsigned r;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
 
 template <bool RELU, bool FLAGS>
 __device__ __forceinline__ void finish_fwd_bf16(const f32x16& acc, bf16x8* dst, unsigned& word, int sh) {
@@ -278,11 +320,8 @@ __device__ __forceinline__ void finish_fwd_bf16(const f32x16& acc, bf16x8* dst, 
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       unsigned x = wv[d];
-      if constexpr (RELU) x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), s16x2{0, 0}));
-      if constexpr (FLAGS) {
-        const unsigned fl = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x), u16x2{1, 1}));
-        word |= fl << (4 * h + d + sh);
-      }
+      if constexpr (RELU) x = pk_relu_bf16(x);
+      if constexpr (FLAGS) word |= pk_nonzero_u16(x) << (4 * h + d + sh);
       wv[d] = x;
     }
     dst[h] = __builtin_bit_cast(bf16x8, wv);
@@ -299,13 +338,42 @@ __device__ __forceinline__ void finish_dgrad_bf16(const f32x16& acc, bf16x8* dst
     if (use_mask) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const unsigned e = (word >> (4 * h + d + sh)) & 0x00010001u;
         const unsigned x = wv[d];   // (bit_cast straight from a vector element reads element 0)
-        wv[d] = __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, e)));
+        wv[d] = pk_mul_u16(x, (word >> (4 * h + d + sh)) & 0x00010001u);
       }
     }
     dst[h] = __builtin_bit_cast(bf16x8, wv);
   }
+}
+
+// ---- saved-activation / d z stores ------------------------------------------------------------
+// Streamed once and read by a later kernel -> non-temporal.  Inline asm with an SGPR base + 32-bit lane
+// offset (the compiler kept a 64-bit vector pointer per store stream and advanced it with two VALU
+// instructions per store), and — as important — invisible to the compiler's waitcnt bookkeeping: with
+// loads and stores pending on the one gfx9 vmcnt it assumes out-of-order completion and drains the
+// counter (vmcnt(0): every outstanding store AND the whole DMA queue) in front of each use of a loaded
+// value.  Hidden stores only make its counted waits stricter.  The data registers are read when the
+// store issues; the listing check covers the rest.
+template <int OFF, class V>
+__device__ __forceinline__ void store16_stream(const char* sbase, uint32_t voff, const V& v) {
+  static_assert(sizeof(V) == 16 && OFF >= 0 && OFF < 4096, "one global_store_dwordx4, 12-bit offset");
+  // s_nop: a store of more than 8 bytes still reads its data one cycle after it issues, and the compiler
+  // (which would insert this wait state for a store it knows) may overwrite the registers right away
+  // leading s_nop 4: the base may have been produced by a VALU instruction (v_readlane of a spilled SGPR,
+  // v_readfirstlane), which a VMEM instruction may read only 5 wait states later; again the compiler
+  // guarantees that only for memory instructions it knows.
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 0" ::"v"(voff), "v"(v), "s"(sbase), "n"(OFF));
+}
+
+// frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section tile (layout [frag][32 samples][32 B], odd frags
+// with the act_row swizzle): output tile nt's share of a stage's deferred stores
+template <int P, int N, int NT, class Frag>
+__device__ __forceinline__ void store_tile_slice(const char* tile_base, const Frag* src, int nt, uint32_t lane_even, uint32_t lane_odd) {
+  static_for<0, N>([&](auto F_) {
+    constexpr int f = decltype(F_)::value;
+    if (f >= N * nt / NT && f < N * (nt + 1) / NT)
+      store16_stream<(f % 4) * 1024>(tile_base + (f / 4) * 4096, (f & 1) ? lane_odd : lane_even, src[f]);
+  });
 }
 
 // sin/cos encoding of one 3-vector into KS frags (mlp_layout.h: enc_slot_feature)

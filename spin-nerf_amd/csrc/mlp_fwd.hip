@@ -185,18 +185,16 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     // arithmetic per store.
     const uint32_t lane_even = g * 16 + sj * 32, lane_odd = g * 16 + act_row<P>(sj, 1) * 32;
     auto sec_base = [&](int k_sec, int64_t tile, int n) {
+#if SNR_ABLATE & 32   // timing experiment: every store hits the same 16 KiB per wave (no HBM traffic)
+      return a.act + (int64_t)wave * 16384;
+#endif
       return a.act + (AL.n_tiles * k_sec + tile * n) * 1024;
     };
     auto act_store = [&](int k_sec, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
       constexpr int n = decltype(N_)::value, stride = decltype(STRIDE_)::value, NT = decltype(NT_)::value;
 #pragma unroll
-      for (int jt = 0; jt < NJ; ++jt) {
-        char* base = sec_base(k_sec, tile0 + jt, n);
-#pragma unroll
-        for (int f = 0; f < n; ++f)
-          if (f >= n * nt / NT && f < n * (nt + 1) / NT)
-            __builtin_nontemporal_store(src[jt * stride + f], (Frag*)(base + f * 1024 + (size_t)((f & 1) ? lane_odd : lane_even)));
-      }
+      for (int jt = 0; jt < NJ; ++jt)
+        store_tile_slice<P, n, NT>(sec_base(k_sec, tile0 + jt, n), src + jt * stride, nt, lane_even, lane_odd);
     };
     using I4 = std::integral_constant<int, 4>;
     using I8 = std::integral_constant<int, 8>;
@@ -204,7 +202,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     using IH9 = std::integral_constant<int, KS_H9>;
     auto mask_store = [&](int k_sec, const u32x4* mk) {
 #pragma unroll
-      for (int jt = 0; jt < NJ; ++jt) *(u32x4*)(sec_base(k_sec, tile0 + jt, 1) + (size_t)(lane * 16u)) = mk[jt];
+      for (int jt = 0; jt < NJ; ++jt) store16_stream<0>(sec_base(k_sec, tile0 + jt, 1), lane * 16u, mk[jt]);
     };
 
     Frag hA[NJ][KS_H], hB[NJ][KS_H];
