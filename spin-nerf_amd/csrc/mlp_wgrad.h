@@ -127,6 +127,8 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
   int64_t src_tile = L.t0;
   auto issue_piece = [&](int slot, int k) {
     // (non-temporal aux = 2 measured no faster: 0.76 vs 0.74 ms)
+    // (s_nop: no LDS read may sit in the cycle in front of an LDS-DMA — mlp_device.h, Pipe::issue_one)
+    if (k < ni) asm volatile("s_nop 0");
     if (k < ni) __builtin_amdgcn_global_load_lds(src[k], SNR_LDS(smem + slot * SLOT + lds_off[k]), 16, 0, SNR_WGRAD_AUX);
   };
   auto advance = [&]() {   // past the end the last tile is re-loaded: the instruction count stays uniform
@@ -357,10 +359,16 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad) {
   if (cb >= J.b_ks * 2 * Prec<P>::EPF) return;
   const int k = slot_true_index<P>(J.b_kind, cb, J.b_kind == SRC_ENC_DIR ? a.L_dir : a.L_pts);
   if (k < 0 || k >= J.cols_valid) return;
-  float s = 0.f;
+  // four independent partial sums: the loads of a thread are otherwise issued one round trip at a time
   const float* p = a.part + J.part_off + (int64_t)ra * NB + cb;
-  for (int sp = 0; sp < J.n_splits; ++sp) s += p[(int64_t)sp * NA * NB];
-  grad[J.w_off + (int64_t)n * J.ld + J.col_off + k] += s;
+  const int64_t st = (int64_t)NA * NB;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int sp = 0;
+  for (; sp + 4 <= J.n_splits; sp += 4) {
+    s0 += p[(sp + 0) * st]; s1 += p[(sp + 1) * st]; s2 += p[(sp + 2) * st]; s3 += p[(sp + 3) * st];
+  }
+  for (; sp < J.n_splits; ++sp) s0 += p[sp * st];
+  grad[J.w_off + (int64_t)n * J.ld + J.col_off + k] += (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -410,21 +418,46 @@ static WgradArgs make_jobs(const snr_mlp_config* c, int64_t n_samples, int64_t* 
     add(WL.off_dout(), 1, SRC_OUT, 1, AL.off_h(7), B::KS_H, SRC_H, 8, L.w_out, kW, 0, 0, c->out_ch, kW, L.b_out);
   }
   A.n_jobs = n;
-  // split-K: the kernel streams saved activations once, so give each job workgroups in proportion
-  // to the bytes it streams; ~2 workgroups per CU in total
+  // split-K: the kernel streams saved activations once and is bound by that stream, so every workgroup
+  // gets the same number of bytes: job i receives target * bytes_i / bytes workgroups, apportioned by
+  // largest remainder so that the total is exactly one workgroup per CU — measured on MI355X (bench
+  // workload): 224-256 workgroups 0.57 ms wgrad + 0.04 ms reduce per step, 512 (two rounds, twice the
+  // partial sums) 0.59 + 0.08, 128 0.84.  SNR_WGRAD_SPLITS overrides the total for experiments.
   const int64_t n_steps = A.n_tiles;
   int64_t cost = 0;
   for (int i = 0; i < n; ++i) cost += A.job[i].a_ks + A.job[i].b_ks;
-  // total workgroups: more than one per CU so that the dispatcher evens out the jobs' different
-  // cost per byte (tunable for experiments through SNR_WGRAD_SPLITS)
-  int target = 512;
+  int target = 256;
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      target = cus;
+    else
+      (void)hipGetLastError();   // no device (size queries on a CPU-only host): keep the default
+  }
   if (const char* e = getenv("SNR_WGRAD_SPLITS")) target = atoi(e) > 0 ? atoi(e) : target;
+  if (target < n) target = n;
+  int64_t rem[kMaxJobs];
+  int assigned = 0;
+  for (int i = 0; i < n; ++i) {
+    const int64_t num = (int64_t)target * (A.job[i].a_ks + A.job[i].b_ks);
+    int64_t s = num / cost;
+    rem[i] = num % cost;
+    if (s < 1) { s = 1; rem[i] = -1; }
+    A.job[i].n_splits = (int)s;
+    assigned += (int)s;
+  }
+  while (assigned < target) {   // hand the left-over workgroups to the largest remainders
+    int best = 0;
+    for (int i = 1; i < n; ++i) if (rem[i] > rem[best]) best = i;
+    if (rem[best] < 0) break;
+    ++A.job[best].n_splits; rem[best] = -1; ++assigned;
+  }
   int sb = 0;
   int64_t po = 0;
   for (int i = 0; i < n; ++i) {
     WgradJob& J = A.job[i];
-    int64_t s = ((int64_t)target * (J.a_ks + J.b_ks) + cost / 2) / cost;
-    if (s < 1) s = 1;
+    int64_t s = J.n_splits;
     if (s > n_steps) s = n_steps;
     J.n_splits = (int)s; J.split_begin = sb; sb += (int)s;
     J.part_off = po; po += s * J.nta * 32 * J.ntb * 32;
