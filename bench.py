@@ -203,12 +203,12 @@ def main():
     dom = max((k for k in kernels if k in flops), key=lambda k: kernels[k]["ms_per_step"])
     peak = PEAK_TFLOPS[ns.precision]
     launches = kernels[dom]["launches_per_step"]
-    # HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r01_summary.md:
+    # HBM bytes per (average) launch of the dominant kernel from the committed PMC passes (profiles/r01_summary.md:
     # 2 x FETCH_SIZE + WRITE_SIZE KiB, gfx950 correction per MI355X_MICROARCH.md); valid for the default workload
     traffic = None
     default_cfg = (ns.precision == "bf16" and ns.n_rand == 1024 and ns.n_coarse == 64 and ns.n_fine == 128)
     if default_cfg and dom == "mlp_wgrad":
-        traffic = (2 * 7.28e5 + 1.04e5) * 1024
+        traffic = (2 * 7.288e5 + 5.194e4) * 1024
     roofline = {
         "kernel": dom, "bound": "mfma",
         "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kernels[dom]["tflops"] / peak,
@@ -216,6 +216,21 @@ def main():
         "flops_per_launch": flops[dom] * evals_per_step / launches,
         "avg_launch_ms": kernels[dom]["ms_per_step"] / launches,
     }
+    # SURVEY.md §8(d) prices the MLP against MFMA.  As built, the three training kernels stream the saved
+    # activations / d z through HBM: bytes each must move per sample (bf16, viewdirs), and
+    # the fraction of the 8 TB/s HBM peak that is while the kernel runs.
+    if ns.precision == "bf16":
+        wg_elems = ((256 + 64) + 6 * 512 + (256 + 64) + 512 + 512 + (16 + 256) + (128 + 256) + (128 + 32) + (16 + 128))
+        stream_bytes = {"mlp_wgrad": 2 * wg_elems,                               # every (d z, activation) pair read once
+                        "mlp_fwd": 2 * (64 + 8 * 256 + 32 + 256 + 128) + 9 * 32,  # encodings, h0..h7, feat, h9, flags
+                        "mlp_dgrad": 2 * (16 + 8 * 256 + 256 + 128) + 9 * 32}     # d out, d z0..7, d feat, d z9 (+ flags read)
+        for k, b in stream_bytes.items():
+            if k in kernels:
+                gbps = b * evals_per_step / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
+                kernels[k]["stream_GBps"] = gbps
+        roofline["stream"] = {"bytes_per_launch": stream_bytes[dom] * evals_per_step / launches,
+                              "achieved": kernels[dom]["stream_GBps"], "peak": 8000.0, "unit": "GB/s",
+                              "frac": kernels[dom]["stream_GBps"] / 8000.0}
     step_flops = 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) * evals_per_step
     out = {
         "metric": "training rays/sec", "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": ns.steps,

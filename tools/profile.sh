@@ -9,10 +9,10 @@ OUT=gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 BENCH="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-frame"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o bench -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_trace.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_INSTS_MFMA \
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o bench -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_trace.err
+timeout -k 5 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_INSTS_MFMA \
   --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_sq -o pmc -- $BENCH > /dev/null 2> $OUT/${TAG}_pmc_sq.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o pmc -- $BENCH > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o pmc -- $BENCH > /dev/null 2> $OUT/${TAG}_pmc_write.err
+timeout -k 5 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o pmc -- $BENCH > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
+timeout -k 5 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o pmc -- $BENCH > /dev/null 2> $OUT/${TAG}_pmc_write.err
 python3 tools/profile_summary.py $OUT $TAG > $OUT/${TAG}_summary.md
 cat $OUT/${TAG}_summary.md
