@@ -189,6 +189,10 @@ def main():
             torch.cuda.synchronize()
             ms_frame = (time.perf_counter() - tf) / nf * 1e3
 
+    if world > 1:   # leave together: rank 0 may still have been rendering its frame
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     n_c, n_f = ns.n_rand * ns.n_coarse, ns.n_rand * (ns.n_coarse + ns.n_fine)
