@@ -169,7 +169,10 @@ template <int P, int WAVES_> struct Pipe {
   template <int KA, int KB, int NT, int NJ, int SA, int SB, class Init, class Finish, class Pre>
   __device__ __forceinline__ void run_tiles(const Frag* sa, const Frag* sb, Init&& init, Finish&& finish, Pre&& pre) {
     constexpr int K = KA + KB, NF = NT * K;
-    constexpr int G0 = (P == kBF16 && NJ == 1 && WAVES == 4) ? 8 : 4;
+#ifndef SNR_WINDOW
+#define SNR_WINDOW 4   // fragments in flight per wave; measured 4 / 6 / 8: 0.214 / 0.219 / 0.241 ms inference (6, 8 spill), dgrad flat
+#endif
+    constexpr int G0 = (P == kBF16) ? SNR_WINDOW : 4;
     constexpr int G = G0 < NF ? G0 : NF;
     constexpr bool OVERLAP = WAVES == 4;   // two waves per SIMD overlap each other; no need to hold two accumulators
     constexpr bool BIAS = !std::is_same_v<decltype(init(0)), f32x16>;

@@ -1,0 +1,151 @@
+"""GPU: size-independent properties at BASELINE.json's full sizes (1024 rays x (64 + 128) samples = 196 608 +
+65 536 MLP evaluations per step, bf16), where the CPU oracle would take minutes:
+
+  * tiling invariance — the fused kernel on 196 608 samples in one launch equals the same samples pushed
+    through in ragged pieces (different workgroup / tile assignment, padding tails);
+  * determinism — two launches give bit-identical outputs and gradients (no atomics anywhere);
+  * linearity of the backward in d raw — grad(a * d) = a * grad(d) and grad(d1 + d2) = grad(d1) + grad(d2)
+    up to bf16 rounding of d z (the forward activations and ReLU flags are shared);
+  * a slice of the big launch equals the CPU oracle's bf16 emulation on that slice (same rounding points);
+  * the full training step at bench size: finite, loss goes down, both networks move.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from helpers import T
+
+pytestmark = pytest.mark.gpu
+
+N_RAYS, N_C, N_F = 1024, 64, 128
+M_FINE = N_RAYS * (N_C + N_F)
+
+
+@pytest.fixture(scope="module")
+def S():
+    import spin_nerf_amd as S
+    assert torch.cuda.is_available()
+    S._lib.load()
+    return S
+
+
+def _net(S, seed, precision="bf16"):
+    sd = O.make_wild_params(seed=seed)
+    net = S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True, precision=precision).cuda()
+    net.load_state_dict(sd)
+    return sd, net
+
+
+def _inputs(seed, n_rays=N_RAYS, s=N_C + N_F):
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand(n_rays, s, 3, generator=g) * 4 - 2).cuda()
+    dirs = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1).cuda()
+    return pts, dirs
+
+
+def test_forward_is_tiling_invariant_and_deterministic(S):
+    _, net = _net(S, 11)
+    pts, dirs = _inputs(1)
+    with torch.no_grad():
+        whole = net.query(pts, dirs)
+        again = net.query(pts, dirs)
+        assert torch.equal(whole, again)
+        # ragged pieces: 1, 7, 250, 33 rays ... (tile tails of 192 * k mod 256 samples)
+        cuts = [0, 1, 8, 258, 291, 700, 1023, N_RAYS]
+        parts = [net.query(pts[a:b], dirs[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert torch.equal(whole, torch.cat(parts, 0))
+    assert torch.isfinite(whole).all()
+
+
+def test_slice_of_full_launch_matches_bf16_emulation(S):
+    sd, net = _net(S, 12)
+    pts, dirs = _inputs(2)
+    with torch.no_grad():
+        whole = net.query(pts, dirs)
+    rows = [0, 1, 511, 1023]
+    p = pts[rows].cpu()
+    d = dirs[rows].cpu()
+    x = torch.cat([O.embed(p.reshape(-1, 3), 10), O.embed(d[:, None].expand(p.shape).reshape(-1, 3), 4)], -1)
+    ref = O.nerf_forward_bf16emu(sd, x, use_viewdirs=True).reshape(len(rows), -1, 4)
+    got = whole[rows].cpu()
+    # same rounding points; what differs is fp32 summation order inside the MFMA and the hardware sin/cos
+    err = (got - ref).abs()
+    scale = ref.abs().mean()
+    assert float(err.mean() / scale) < 2e-2, float(err.mean() / scale)
+    assert float(err.max() / scale) < 0.5, float(err.max() / scale)
+
+
+def _grad(net, pts, dirs, d_raw):
+    net.flat.grad = None
+    out = net.query(pts, dirs)
+    out.backward(d_raw)
+    return net.flat.grad.clone()
+
+
+def test_backward_is_deterministic_and_linear_in_d_raw(S):
+    _, net = _net(S, 13)
+    pts, dirs = _inputs(3)
+    g = torch.Generator().manual_seed(4)
+    d1 = torch.randn(N_RAYS, N_C + N_F, 4, generator=g).cuda()
+    d2 = torch.randn(N_RAYS, N_C + N_F, 4, generator=g).cuda()
+    g1 = _grad(net, pts, dirs, d1)
+    assert torch.equal(g1, _grad(net, pts, dirs, d1))          # no atomics, fixed split-K order
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    # exact scaling by a power of two (bf16 rounding commutes with it)
+    assert torch.equal(_grad(net, pts, dirs, 4.0 * d1), 4.0 * g1)
+    # additivity up to the bf16 rounding of d z at every layer
+    g2 = _grad(net, pts, dirs, d2)
+    g12 = _grad(net, pts, dirs, d1 + d2)
+    rel = float((g12 - (g1 + g2)).norm() / (g1 + g2).norm())
+    assert rel < 1e-2, rel
+
+
+def test_split_gradient_equals_whole(S):
+    """Backward of 196 608 samples in one launch vs accumulated over two halves (different split-K
+    partition of the samples): equal up to fp32 summation order."""
+    _, net = _net(S, 14)
+    pts, dirs = _inputs(5)
+    d = torch.randn(N_RAYS, N_C + N_F, 4, generator=torch.Generator().manual_seed(6)).cuda()
+    whole = _grad(net, pts, dirs, d)
+    net.flat.grad = None
+    h = N_RAYS // 2
+    net.query(pts[:h], dirs[:h]).backward(d[:h])
+    net.query(pts[h:], dirs[h:]).backward(d[h:])
+    halves = net.flat.grad.clone()
+    rel = float((whole - halves).norm() / whole.norm())
+    assert rel < 1e-5, rel
+
+
+def test_training_step_at_bench_size(S):
+    import argparse, contextlib, io, tempfile
+    RenderTrainer = importlib.import_module("spin-nerf_amd.train").RenderTrainer
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    args = argparse.Namespace(
+        multires=10, multires_views=4, i_embed=0, use_viewdirs=True, N_importance=N_F, N_samples=N_C,
+        alpha_model_path=None, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536,
+        lrate=5e-4, basedir=tempfile.mkdtemp(), expname="", ft_path=None, no_reload=True, perturb=1.0,
+        white_bkgd=True, raw_noise_std=1.0, dataset_type="llff", no_ndc=True, lindisp=True, sigma_loss=False,
+        no_coarse=False, precision="bf16")
+    with contextlib.redirect_stdout(io.StringIO()):
+        kw_train, *_ = S.create_nerf(args, device=dev)
+    kw_train.update(near=1.2, far=9.0)
+    tr = RenderTrainer(kw_train, lrate=5e-4, lrate_decay=250)
+    H, W, focal = 378, 504, 400.0
+    ro, rd = S.get_rays(H, W, focal, torch.eye(4, device=dev)[:3, :4])
+    sel = torch.randperm(H * W, generator=torch.Generator().manual_seed(5))[:N_RAYS].to(dev)
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0).contiguous()
+    target = torch.full((N_RAYS, 3), 0.25, device=dev)
+    before = [n.flat.detach().clone() for n in tr.nets]
+    losses = []
+    for _ in range(30):
+        loss, rgb = tr.step(H, W, focal, rays, target)
+        losses.append(float(loss))
+        assert rgb.shape == (N_RAYS, 3)
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), (losses[:5], losses[-5:])
+    for n, b in zip(tr.nets, before):
+        assert torch.isfinite(n.flat).all() and float((n.flat.detach() - b).abs().max()) > 0
