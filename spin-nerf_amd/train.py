@@ -29,6 +29,16 @@ class RenderTrainer:
         self.global_step = 0
         self.m = [torch.zeros_like(n.flat.data) for n in self.nets]
         self.v = [torch.zeros_like(n.flat.data) for n in self.nets]
+        # The all-reduce of a net's gradient starts the moment autograd has finished that net (the fine net's
+        # runs under the coarse net's backward); apply_gradients() only waits.
+        self._works = {}
+        if world_size > 1:
+            for i, n in enumerate(self.nets):
+                n.flat.register_post_accumulate_grad_hook(lambda p, i=i: self._start_all_reduce(i, p))
+
+    def _start_all_reduce(self, i, p):
+        import torch.distributed as dist
+        self._works[i] = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def broadcast_parameters(self, src=0):
         """identical replicas at start (rank `src`'s init wins)"""
@@ -57,10 +67,12 @@ class RenderTrainer:
     def apply_gradients(self):
         if self.world_size > 1:
             import torch.distributed as dist
-            works = [dist.all_reduce(n.flat.grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                     for n in self.nets]
-            for w in works:
+            for i, n in enumerate(self.nets):   # anything the hooks did not see (gradients set by hand)
+                if i not in self._works:
+                    self._start_all_reduce(i, n.flat)
+            for w in self._works.values():
                 w.wait()
+            self._works.clear()
         self.global_step += 1
         lr = self.current_lr()
         for n, m, v in zip(self.nets, self.m, self.v):

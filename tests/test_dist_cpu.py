@@ -62,6 +62,14 @@ def _worker(rank, world, port, out):
     err_g = float((net.flat.grad / world - g_full).abs().max() / g_full.abs().max())
     if rank == 0:
         torch.save({"flat0": flat0, "flat": net.flat.detach(), "err_g": err_g, "p_ref": p_ref}, out)
+    # second step, gradient through autograd: the post-accumulate hook starts the all-reduce inside backward()
+    net.flat.grad = None
+    c = torch.full_like(net.flat.data, float(rank + 1))
+    (net.flat * c).sum().backward()
+    assert len(tr._works) == 1, "hook did not start the all-reduce"
+    tr.apply_gradients()
+    assert not tr._works
+    assert torch.equal(net.flat.grad, torch.full_like(c, float(sum(range(1, world + 1)))))
     # every rank must hold identical parameters after the step
     gathered = [torch.zeros_like(net.flat.data) for _ in range(world)]
     dist.all_gather(gathered, net.flat.data)
