@@ -64,6 +64,50 @@ class RenderTrainer:
         self.apply_gradients()
         return loss.detach(), rgb.detach()
 
+    def spin_loss(self, H, W, focal, batch_rays_clf, target_clf, batch_rays, target_s, batch_inp=None,
+                  depth_inp=None, chunk=1024 * 32, randoms=None, **extra):
+        """Loss of one SPIn-NeRF iteration in its default mode (run_nerf.py:1455-1521, no --masked_NeRF /
+        --object_removal / --prepare / --no_geometry, LPIPS and COLMAP-depth terms excluded — SURVEY.md §8 f-1):
+
+          render(unmasked-pixel rays)                         -> mse(rgb, target_clf) + mse(rgb0, target_clf)
+          render(all-pixel rays, detach_weights=True)         -> mse(rgb, target_s)   + mse(rgb0, target_s)
+          render(rays with an inpainted-disparity target)     -> MSE(disp, depth_inp) + MSE(disp0, depth_inp),
+                                                                 skipped when NaN like the reference (:1518-1521)
+
+        ``randoms`` = optional list of three injected-random dicts (one per render, as for render()) so that
+        parity tests can pin the draws.  Returns (loss, dict of the three render outputs)."""
+        rnd = randoms or [None, None, None]
+        kw = dict(chunk=chunk, retraw=True, **extra, **self.kw)
+        rgb, disp, acc, depth, ex = render(H, W, focal, rays=batch_rays_clf, randoms=rnd[0], **kw)
+        rgb_c, _, _, _, ex_c = render(H, W, focal, rays=batch_rays, detach_weights=True, randoms=rnd[1], **kw)
+        loss = img2mse(rgb, target_clf) + img2mse(rgb_c, target_s)
+        if 'rgb0' in ex_c:
+            loss = loss + img2mse(ex_c['rgb0'], target_s)
+        if 'rgb0' in ex:
+            loss = loss + img2mse(ex['rgb0'], target_clf)
+        outs = {"clf": (rgb, disp, acc, depth, ex), "complete": (rgb_c, ex_c)}
+        if batch_inp is not None:
+            _, disp_i, _, _, ex_i = render(H, W, focal, rays=batch_inp, randoms=rnd[2], **kw)
+            inp = img2mse(disp_i, depth_inp)
+            if 'disp0' in ex_i:
+                inp = inp + img2mse(ex_i['disp0'], depth_inp)
+            if not bool(torch.isnan(inp)):
+                loss = loss + inp
+            outs["inp"] = (disp_i, ex_i)
+        return loss, outs
+
+    def spin_iteration(self, *args, **kwargs):
+        """spin_loss + backward + all-reduce + Adam; returns (loss, psnr of the unmasked-pixel render)."""
+        for n in self.nets:
+            n.flat.grad = None
+        loss, outs = self.spin_loss(*args, **kwargs)
+        loss.backward()
+        self.apply_gradients()
+        rgb = outs["clf"][0].detach()
+        target_clf = args[4] if len(args) > 4 else kwargs["target_clf"]
+        mse = img2mse(rgb, target_clf)
+        return loss.detach(), -10.0 * torch.log10(mse)
+
     def apply_gradients(self):
         if self.world_size > 1:
             import torch.distributed as dist
