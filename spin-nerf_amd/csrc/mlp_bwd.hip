@@ -247,8 +247,10 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
                          void* ws, float* grad, int accumulate, hipStream_t s) {
   const PackTable T = make_pack_table<P>(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
   const ParamLayout L = make_param_layout(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
-  if (!accumulate) {
-    hipError_t e = hipMemsetAsync(grad, 0, (size_t)L.total * sizeof(float), s);
+  // The reduce kernel stores every parameter a weight-gradient job produces; the only parameters no job
+  // produces are views_linears.0 of a network without view directions (unused, but part of the state dict).
+  if (!accumulate && !c->use_viewdirs) {
+    hipError_t e = hipMemsetAsync(grad + L.w_views, 0, (size_t)((L.b_views + kW / 2) - L.w_views) * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
   }
   DgradArgs d{};
@@ -280,7 +282,7 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   const int per_job = 256 * 257;
   {
     ProfScope ps(K_MLP_WGRAD_REDUCE, s);
-    mlp_wgrad_reduce_kernel<P><<<dim3((per_job + 255) / 256, (unsigned)w.n_jobs), dim3(256), 0, s>>>(w, grad);
+    mlp_wgrad_reduce_kernel<P><<<dim3((per_job + 255) / 256, (unsigned)w.n_jobs), dim3(256), 0, s>>>(w, grad, accumulate);
   }
   return launch_status();
 }

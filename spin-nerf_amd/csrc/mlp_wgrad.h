@@ -340,7 +340,10 @@ template <int P> __device__ __forceinline__ int slot_true_index(int kind, int x,
 }
 
 template <int P>
-__global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad) {
+__global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, int accumulate) {
+  // Every parameter element a job produces is produced by exactly one (job, row, column): without
+  // `accumulate` the result is stored, not added, and the gradient buffer needs no clearing first
+  // (tests/test_gpu_kernels.py: test_mlp_backward_overwrites_every_element).
   // blockIdx.y = job; threads cover (row, col) plus one extra column (col == NB) for the bias
   const WgradJob& J = a.job[blockIdx.y];
   const int NA = J.nta * 32, NB = J.ntb * 32;
@@ -354,7 +357,7 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad) {
     if (J.bias_off < 0) return;
     float s = 0.f;
     for (int sp = 0; sp < J.n_splits; ++sp) s += a.part[J.bias_part_off + (int64_t)sp * NA + ra];
-    grad[J.bias_off + n] += s;
+    grad[J.bias_off + n] = accumulate ? grad[J.bias_off + n] + s : s;
     return;
   }
   if (cb >= J.b_ks * 2 * Prec<P>::EPF) return;
@@ -369,7 +372,9 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad) {
     s0 += p[(sp + 0) * st]; s1 += p[(sp + 1) * st]; s2 += p[(sp + 2) * st]; s3 += p[(sp + 3) * st];
   }
   for (; sp < J.n_splits; ++sp) s0 += p[sp * st];
-  grad[J.w_off + (int64_t)n * J.ld + J.col_off + k] += (s0 + s1) + (s2 + s3);
+  float* g = grad + J.w_off + (int64_t)n * J.ld + J.col_off + k;
+  const float s = (s0 + s1) + (s2 + s3);
+  *g = accumulate ? *g + s : s;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -64,11 +64,14 @@ class _Composite(torch.autograd.Function):
                                         ptr(alpha), stream()), "snr_composite_forward")
         ctx.save_for_backward(raw_c, z, r, nz)
         ctx.flags = (int(bool(white_bkgd)), int(bool(detach_weights)), need_alpha)
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None (= the kernel's NULL), not as zero fills
         return rgb, disp, acc, depth, w, alpha
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_w, g_alpha):
         lib = _lib.load()
+        if all(g is None for g in (g_rgb, g_disp, g_acc, g_depth, g_w, g_alpha)):
+            return None, None, None, None, None, None, None
         raw, z, r, nz = ctx.saved_tensors
         white, detach, need_alpha = ctx.flags
         n, S, C = raw.shape
@@ -146,10 +149,14 @@ class _Mlp(torch.autograd.Function):
               "snr_mlp_forward")
         ctx.net, ctx.n_samples = net, n_samples
         ctx.act, ctx.packed = act, packed
+        ctx.set_materialize_grads(False)
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
+        if d_raw is None:
+            ctx.act = None
+            return None, None, None, None, None, None, None, None
         lib = _lib.load()
         net, n = ctx.net, ctx.n_samples
         cfg = net.cfg

@@ -126,7 +126,8 @@ def render_rays(ray_batch,
             return n
         if pytest:                                            # helpers:377-380 (uniform, not normal)
             return _pytest_rand([N_rays, S], dev) * raw_noise_std
-        return torch.randn(N_rays, S, device=dev) * raw_noise_std
+        n = torch.randn(N_rays, S, device=dev)
+        return n if raw_noise_std == 1. else n * raw_noise_std
 
     def composite(raw, z, noise):
         rgb, disp, acc, depth, w, alpha = ops._Composite.apply(raw, z, ray_batch, noise, white_bkgd, detach_weights,

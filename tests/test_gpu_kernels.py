@@ -298,6 +298,34 @@ def test_mlp_backward_bf16(S, vd, wild):
         assert rel < 0.3 and cos > 0.95, f"{k}: vs fp32 autograd: relative L2 error {rel:.2e}, cosine {cos:.4f}"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("vd", [True, False])
+def test_mlp_backward_overwrites_every_element(S, vd, precision):
+    """C ABI contract of snr_mlp_backward: accumulate=0 stores into every element of the gradient buffer (no
+    clearing needed, nothing left behind — checked on a NaN-poisoned buffer), accumulate=1 adds to it."""
+    L = S._lib
+    lib = L.load()
+    sd = O.make_wild_params(seed=9, use_viewdirs=vd, output_ch=4 if vd else 5, input_ch_views=27 if vd else 0)
+    net = make_net(S, sd, vd, precision, out_ch=4 if vd else 5)
+    n = 37 * 9
+    rs = np.random.RandomState(3)
+    pts = torch.from_numpy(rs.uniform(-2, 2, size=(n, 3)).astype(np.float32)).cuda()
+    dirs = torch.nn.functional.normalize(torch.from_numpy(rs.normal(size=(n, 3)).astype(np.float32)), dim=-1).cuda()
+    cfg, packed = net.cfg, net.packed_weights()
+    raw = torch.empty(n, cfg.out_ch, device="cuda")
+    act = torch.empty(lib.snr_mlp_act_bytes(cfg, n), dtype=torch.uint8, device="cuda")
+    L.check(lib.snr_mlp_forward(cfg, L.ptr(packed), L.ptr(pts), None, 0, None, L.ptr(dirs) if vd else None, 3, n, 1,
+                                L.ptr(raw), L.ptr(act), L.stream()), "fwd")
+    d_raw = torch.from_numpy(rs.normal(size=(n, cfg.out_ch)).astype(np.float32)).cuda()
+    ws = torch.empty(lib.snr_mlp_bwd_ws_bytes(cfg, n), dtype=torch.uint8, device="cuda")
+    g = torch.full_like(net.flat.data, float("nan"))
+    L.check(lib.snr_mlp_backward(cfg, L.ptr(packed), L.ptr(d_raw), n, L.ptr(act), L.ptr(ws), L.ptr(g), 0, L.stream()), "bwd")
+    assert torch.isfinite(g).all(), int((~torch.isfinite(g)).sum())
+    g2 = g.clone()
+    L.check(lib.snr_mlp_backward(cfg, L.ptr(packed), L.ptr(d_raw), n, L.ptr(act), L.ptr(ws), L.ptr(g2), 1, L.stream()), "bwd")
+    close(g2, 2 * g, atol=1e-6 * float(g.abs().max()), rtol=1e-6)
+
+
 def test_mlp_backward_accumulates_over_calls(S):
     """Three render() calls per reference iteration (run_nerf.py:1455-1470) -> grads add up."""
     sd = O.make_wild_params(seed=7)
