@@ -121,6 +121,17 @@ int snr_sample_fine(const float* z_coarse, const float* weights, const float* u,
 int snr_make_rays(int H, int W, float focal, const float* c2w_host, int i0, int j0, int h, int w, int ndc,
                   float near, float far, int use_viewdirs, float* rays, int ray_ld, snr_stream_t stream);
 
+/* Same rows from rays the caller already holds (render(rays=...), run_nerf.py:117-153 incl. the viewdir
+ * normalisation :128-135 and ndc_rays :140): rays_o, rays_d [n_rays,3] contiguous device memory. */
+int snr_pack_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int H, int W, float focal, int ndc,
+                  float near, float far, int use_viewdirs, float* rays, int ray_ld, snr_stream_t stream);
+
+/* ---- loss of one training step: replaces img2mse(rgb, target) [+ img2mse(rgb0, target)] and its autograd
+ * (helpers:15, run_nerf.py:1482-1490).  a, b (may be NULL), target: n elements each.  loss[0] = the sum of the
+ * two means, loss[1] = mean((a - target)^2) alone; grad_a / grad_b = d loss / d a, d b. */
+int snr_mse_pair(const float* a, const float* b, const float* target, int64_t n, float* loss, float* grad_a,
+                 float* grad_b, snr_stream_t stream);
+
 /* ---- Adam on the flat parameter buffer: replaces torch.optim.Adam(lr, betas=(0.9,0.999))
  * (run_nerf.py:433-434, 1611-1612).  step is 1-based. grad_scale multiplies g first
  * (1/world_size for data-parallel sums). */

@@ -326,22 +326,10 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 struct Pose { float m[12]; };
 
-__global__ void make_rays_kernel(int H, int W, float focal, Pose c2w, int i0, int j0, int h, int w, int ndc,
-                                 float near, float far, int use_viewdirs, float* __restrict__ rays, int ld) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)h * w) return;
-  const int row = i0 + (int)(idx / w), col = j0 + (int)(idx % w);
-  // dirs = [(i - W/2)/f, -(j - H/2)/f, -1]; d = sum(dirs * c2w[:3,:3], -1); o = c2w[:3,3]
-  const float dx = ((float)col - (float)W * .5f) / focal;
-  const float dy = -((float)row - (float)H * .5f) / focal;
-  const float dz = -1.f;
-  float d[3], o[3];
-  for (int r = 0; r < 3; ++r) {
-    d[r] = dx * c2w.m[4 * r] + dy * c2w.m[4 * r + 1] + dz * c2w.m[4 * r + 2];
-    o[r] = c2w.m[4 * r + 3];
-  }
-  float* out = rays + idx * ld;
-  if (use_viewdirs) {  // normalised BEFORE the NDC warp (run_nerf.py:128-135)
+// one packed row [o d near far (viewdirs)]: viewdirs normalised BEFORE the NDC warp (run_nerf.py:128-135)
+__device__ __forceinline__ void write_ray_row(float* o, float* d, int H, int W, float focal, int ndc, float near,
+                                              float far, int use_viewdirs, float* __restrict__ out) {
+  if (use_viewdirs) {
     const float n = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     out[8] = d[0] / n; out[9] = d[1] / n; out[10] = d[2] / n;
   }
@@ -357,6 +345,68 @@ __global__ void make_rays_kernel(int H, int W, float focal, Pose c2w, int i0, in
   out[0] = o[0]; out[1] = o[1]; out[2] = o[2];
   out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
   out[6] = near; out[7] = far;
+}
+
+__global__ void make_rays_kernel(int H, int W, float focal, Pose c2w, int i0, int j0, int h, int w, int ndc,
+                                 float near, float far, int use_viewdirs, float* __restrict__ rays, int ld) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)h * w) return;
+  const int row = i0 + (int)(idx / w), col = j0 + (int)(idx % w);
+  // dirs = [(i - W/2)/f, -(j - H/2)/f, -1]; d = sum(dirs * c2w[:3,:3], -1); o = c2w[:3,3]
+  const float dx = ((float)col - (float)W * .5f) / focal;
+  const float dy = -((float)row - (float)H * .5f) / focal;
+  const float dz = -1.f;
+  float d[3], o[3];
+  for (int r = 0; r < 3; ++r) {
+    d[r] = dx * c2w.m[4 * r] + dy * c2w.m[4 * r + 1] + dz * c2w.m[4 * r + 2];
+    o[r] = c2w.m[4 * r + 3];
+  }
+  write_ray_row(o, d, H, W, focal, ndc, near, far, use_viewdirs, rays + idx * ld);
+}
+
+// rows from rays the caller already holds (render(rays=...), run_nerf.py:117-153): same row as above
+__global__ void pack_rays_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, int64_t n,
+                                 int H, int W, float focal, int ndc, float near, float far, int use_viewdirs,
+                                 float* __restrict__ rays, int ld) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float o[3] = {rays_o[3 * idx], rays_o[3 * idx + 1], rays_o[3 * idx + 2]};
+  float d[3] = {rays_d[3 * idx], rays_d[3 * idx + 1], rays_d[3 * idx + 2]};
+  write_ray_row(o, d, H, W, focal, ndc, near, far, use_viewdirs, rays + idx * ld);
+}
+
+// ------------------------------------------------------------------------------------------
+// loss of the training step: mean((rgb - t)^2) [+ mean((rgb0 - t)^2)] and its gradients
+// (img2mse, helpers:15; run_nerf.py:1482-1490).  One workgroup: 3 * N_rand elements.
+// ------------------------------------------------------------------------------------------
+__global__ void mse_pair_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ t,
+                                int64_t n, float* __restrict__ loss, float* __restrict__ ga, float* __restrict__ gb) {
+  __shared__ float red[2][16];
+  float sa = 0.f, sb = 0.f;
+  const float inv = 1.f / (float)n;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const float da = a[i] - t[i];
+    sa += da * da;
+    ga[i] = 2.f * da * inv;
+    if (b) {
+      const float db = b[i] - t[i];
+      sb += db * db;
+      gb[i] = 2.f * db * inv;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    sa += __shfl_down(sa, off, 64);
+    sb += __shfl_down(sb, off, 64);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[0][wave] = sa; red[1][wave] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ta = 0.f, tb = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ta += red[0][w]; tb += red[1][w]; }
+    loss[0] = ta * inv + tb * inv;
+    loss[1] = ta * inv;   // the fine term alone (PSNR of the reference's log line)
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -484,6 +534,27 @@ extern "C" int snr_make_rays(int H, int W, float focal, const float* c2w_host, i
     make_rays_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
         H, W, focal, p, i0, j0, h, w, ndc, near, far, use_viewdirs, rays, ld);
   }
+  return launch_status();
+}
+
+extern "C" int snr_pack_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int H, int W, float focal,
+                             int ndc, float near, float far, int use_viewdirs, float* rays, int ld,
+                             snr_stream_t stream) {
+  SNR_CHECK_ARG(rays_o && rays_d && rays, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_rays > 0 && H > 0 && W > 0 && ld >= (use_viewdirs ? 11 : 8), SNR_ERR_SHAPE);
+  {
+    ProfScope ps(K_MAKE_RAYS, (hipStream_t)stream);
+    pack_rays_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        rays_o, rays_d, n_rays, H, W, focal, ndc, near, far, use_viewdirs, rays, ld);
+  }
+  return launch_status();
+}
+
+extern "C" int snr_mse_pair(const float* a, const float* b, const float* target, int64_t n, float* loss,
+                            float* grad_a, float* grad_b, snr_stream_t stream) {
+  SNR_CHECK_ARG(a && target && loss && grad_a && (!b || grad_b), SNR_ERR_NULL);
+  SNR_CHECK_ARG(n > 0, SNR_ERR_SHAPE);
+  mse_pair_kernel<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(a, b, target, n, loss, grad_a, grad_b);
   return launch_status();
 }
 

@@ -125,6 +125,30 @@ def make_rays(H, W, focal, c2w, patch=None, ndc=True, near=0., far=1., use_viewd
     return rays
 
 
+def pack_rays(rays_o, rays_d, H, W, focal, ndc=True, near=0., far=1., use_viewdirs=False):
+    """Packed rows for rays the caller already holds: one kernel instead of norm / div / ones / cat."""
+    lib = _lib.load()
+    o, d = f32c(rays_o.detach().reshape(-1, 3)), f32c(rays_d.detach().reshape(-1, 3))
+    ld = 11 if use_viewdirs else 8
+    rays = torch.empty(o.shape[0], ld, device=o.device, dtype=torch.float32)
+    check(lib.snr_pack_rays(ptr(o), ptr(d), o.shape[0], int(H), int(W), float(focal), int(bool(ndc)), float(near),
+                            float(far), int(bool(use_viewdirs)), ptr(rays), ld, stream()), "snr_pack_rays")
+    return rays
+
+
+def mse_pair(a, b, target):
+    """(loss, fine-term, d loss/d a, d loss/d b) for loss = mean((a-t)^2) [+ mean((b-t)^2)] in one launch."""
+    lib = _lib.load()
+    a_c, t_c = f32c(a.detach()), f32c(target.detach())
+    b_c = f32c(b.detach()) if b is not None else None
+    loss = torch.empty(2, device=a_c.device, dtype=torch.float32)
+    ga = torch.empty_like(a_c)
+    gb = torch.empty_like(b_c) if b_c is not None else None
+    check(lib.snr_mse_pair(ptr(a_c), ptr(b_c), ptr(t_c), a_c.numel(), ptr(loss), ptr(ga), ptr(gb), stream()),
+          "snr_mse_pair")
+    return loss[0], loss[1], ga, gb
+
+
 # ----------------------------------------------------------------------------------------------
 # NeRF MLP (run_nerf.py:56-71; helpers:104-127)
 # ----------------------------------------------------------------------------------------------

@@ -223,6 +223,13 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True,
         rays_flat = ops.make_rays(H, W, focal, c2w, patch=pr, ndc=ndc, near=float(near), far=float(far),
                                   use_viewdirs=use_viewdirs, device=dev)
         sh = (pr[2], pr[3], 3) if pr is not None else (H, W, 3)
+    elif (c2w is None and c2w_staticcam is None and depths is None and not isinstance(near, torch.Tensor)
+          and not isinstance(far, torch.Tensor) and rays[1].is_cuda):
+        # rays the caller holds: viewdir normalisation, NDC warp and the packing in one kernel
+        rays_o, rays_d = rays
+        sh = rays_d.shape
+        rays_flat = ops.pack_rays(rays_o, rays_d, H, W, focal, ndc=ndc, near=float(near), far=float(far),
+                                  use_viewdirs=use_viewdirs)
     else:
         if c2w is not None:
             rays_o, rays_d = get_rays(H, W, focal, c2w)

@@ -57,12 +57,16 @@ class RenderTrainer:
             n.flat.grad = None
         rgb, disp, acc, depth, extras = render(H, W, focal, chunk=chunk, rays=batch_rays, retraw=True,
                                                **extra, **self.kw)
-        loss = img2mse(rgb, target_s)                         # run_nerf.py:1482
-        if 'rgb0' in extras:
-            loss = loss + img2mse(extras['rgb0'], target_s)   # run_nerf.py:1488-1490
-        loss.backward()
+        # loss = img2mse(rgb, target) + img2mse(rgb0, target) (run_nerf.py:1482-1490) and its gradients in one
+        # launch; autograd takes over at the render outputs
+        rgb0 = extras.get('rgb0')
+        loss, _, g_rgb, g_rgb0 = ops.mse_pair(rgb, rgb0, target_s)
+        if rgb0 is not None:
+            torch.autograd.backward([rgb, rgb0], [g_rgb, g_rgb0])
+        else:
+            torch.autograd.backward([rgb], [g_rgb])
         self.apply_gradients()
-        return loss.detach(), rgb.detach()
+        return loss, rgb.detach()
 
     def spin_loss(self, H, W, focal, batch_rays_clf, target_clf, batch_rays, target_s, batch_inp=None,
                   depth_inp=None, chunk=1024 * 32, randoms=None, **extra):

@@ -338,3 +338,43 @@ def test_mlp_backward_accumulates_over_calls(S):
     net.flat.grad = None
     (net.query(pts, dirs).sum() + net.query(pts, dirs).sum()).backward()
     close(net.flat.grad, 2 * g1, atol=1e-6 * float(g1.abs().max()), rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# ray packing for caller-held rays, training-step loss
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ndc", [True, False])
+@pytest.mark.parametrize("vd", [True, False])
+def test_pack_rays_matches_reference_row_layout(S, ndc, vd):
+    """snr_pack_rays vs the oracle's restatement of render()'s ray preparation (run_nerf.py:117-153):
+    viewdirs normalised before the NDC warp, rows [o d near far (viewdirs)]."""
+    H, W, focal, near, far = 18, 24, 20.0, 0.25, 3.5
+    rs = np.random.RandomState(4)
+    o = torch.from_numpy(rs.uniform(-1, 1, size=(77, 3)).astype(np.float32))
+    d = torch.from_numpy(rs.normal(size=(77, 3)).astype(np.float32))
+    d[:, 2] = -d[:, 2].abs() - 0.3           # looking down -z like a real camera (NDC divides by d_z)
+    got = S.ops.pack_rays(o.cuda(), d.cuda(), H, W, focal, ndc=ndc, near=near, far=far, use_viewdirs=vd).cpu()
+    vdirs = d / torch.norm(d, dim=-1, keepdim=True)
+    oo, dd = O.ndc_rays(H, W, focal, 1., o, d) if ndc else (o, d)
+    cols = [oo, dd, near * torch.ones_like(dd[..., :1]), far * torch.ones_like(dd[..., :1])] + ([vdirs] if vd else [])
+    ref = torch.cat(cols, -1)
+    assert got.shape == ref.shape
+    close(got, ref, atol=1e-6, rtol=2e-6)
+
+
+@pytest.mark.parametrize("with_coarse", [True, False])
+def test_mse_pair_matches_torch(S, with_coarse):
+    rs = np.random.RandomState(5)
+    a = torch.from_numpy(rs.rand(1024, 3).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rs.rand(1024, 3).astype(np.float32)).requires_grad_(True)
+    t = torch.from_numpy(rs.rand(1024, 3).astype(np.float32))
+    ref = O.img2mse(a, t) + (O.img2mse(b, t) if with_coarse else 0.)
+    ref.backward()
+    loss, fine, ga, gb = S.ops.mse_pair(a.detach().cuda(), b.detach().cuda() if with_coarse else None, t.cuda())
+    close(loss, ref.detach(), atol=0, rtol=2e-6)
+    close(fine, O.img2mse(a, t).detach(), atol=0, rtol=2e-6)
+    close(ga, a.grad, atol=1e-10, rtol=1e-6)
+    if with_coarse:
+        close(gb, b.grad, atol=1e-10, rtol=1e-6)
+    else:
+        assert gb is None
