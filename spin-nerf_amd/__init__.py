@@ -12,11 +12,11 @@ from .nerf import NeRF
 from .ops import raw2outputs, sample_coarse, sample_fine, make_rays, mlp_query, adam_step_
 from .render import (render, render_rays, batchify_rays, batchify, run_network, create_nerf, get_embedder, get_rays,
                      ndc_rays, Embedder)
-from .path import render_path, to8b, write_png
+from .path import render_path, render_sharded, to8b, write_png
 
 img2mse = lambda x, y: ((x - y) ** 2).mean()                      # helpers:15
 mse2psnr = lambda x: -10. * x.log() / 2.302585092994046           # helpers:17
 
 __all__ = ["NeRF", "render", "render_rays", "batchify_rays", "batchify", "run_network", "create_nerf",
            "get_embedder", "get_rays", "ndc_rays", "raw2outputs", "sample_coarse", "sample_fine", "make_rays",
-           "mlp_query", "adam_step_", "img2mse", "mse2psnr", "HipLibraryError", "LIB_PATH", "Embedder", "render_path", "to8b", "write_png"]
+           "mlp_query", "adam_step_", "img2mse", "mse2psnr", "HipLibraryError", "LIB_PATH", "Embedder", "render_path", "render_sharded", "to8b", "write_png"]

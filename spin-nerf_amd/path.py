@@ -109,3 +109,35 @@ def render_path(render_poses, hwf, chunk, render_kwargs, gt_imgs=None, savedir=N
     disps = torch.stack(disps, 0) if disp_require_grad else np.stack(disps, 0)
     rgbs = torch.stack(rgbs, 0) if rgb_require_grad else np.stack(rgbs, 0)
     return rgbs, disps, (Xs, Ys)
+
+
+def render_sharded(H, W, focal, c2w, chunk, render_kwargs, group=None, render_fn=None):
+    """Full frame on all ranks of a process group: rank r renders the row band
+    [r*ceil(H/world), ...) through render()'s patch mode, then one all_gather of [rows, W, 6] =
+    rgb(3) | disp | acc | depth per rank assembles the frame everywhere.  Rays are independent, so this
+    is the only collective of the inference path; without an initialised process group it is render().
+
+    Returns [rgb_map[H,W,3], disp_map[H,W], acc_map[H,W], depth_map[H,W]] (no extras: the per-sample
+    tensors stay on the rank that produced them)."""
+    import torch.distributed as dist
+    render_fn = render_fn or render
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    rows = -(-H // world)                       # rows per rank (the last band may be shorter or empty)
+    i0 = min(rank * rows, H)
+    h = max(0, min(rows, H - i0))
+    dev = c2w.device if isinstance(c2w, torch.Tensor) else torch.device("cpu")
+    band = torch.zeros(rows, W, 6, device=dev, dtype=torch.float32)
+    if h > 0:
+        with torch.no_grad():
+            rgb, disp, acc, depth, _ = render_fn(H, W, focal, chunk=chunk, c2w=c2w[:3, :4], patch=(i0, 0, h, W),
+                                                 **render_kwargs)
+        band[:h, :, 0:3] = rgb
+        band[:h, :, 3], band[:h, :, 4], band[:h, :, 5] = disp, acc, depth
+    if world > 1:
+        parts = [torch.empty_like(band) for _ in range(world)]
+        dist.all_gather(parts, band, group=group)
+        frame = torch.cat(parts, 0)[:H]
+    else:
+        frame = band[:H]
+    return [frame[..., 0:3], frame[..., 3], frame[..., 4], frame[..., 5]]

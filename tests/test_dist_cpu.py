@@ -88,3 +88,41 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     # the parameters moved, and to (nearly) where a single process would have put them
     assert float((r["flat"] - r["flat0"]).abs().max()) > 1e-4
     assert float((r["flat"] - r["p_ref"]).abs().max()) < 2e-4
+
+
+def _sharded_worker(rank, world, port, out):
+    """render_sharded's band arithmetic and all_gather with a stand-in renderer (the HIP kernels need a GPU):
+    the assembled frame must equal the single-process frame for heights that do and do not divide evenly."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import spin_nerf_amd as S
+
+    def fake_render(H, W, focal, chunk=0, c2w=None, patch=None, **kw):
+        i0, j0, h, w = patch
+        ii = torch.arange(i0, i0 + h, dtype=torch.float32)[:, None].expand(h, w)
+        jj = torch.arange(j0, j0 + w, dtype=torch.float32)[None, :].expand(h, w)
+        base = ii * 100 + jj + float(c2w[0, 3])
+        return [torch.stack([base, base + .25, base + .5], -1), base * 2, base * 3, base * 4, {}]
+
+    ok = True
+    for H in (8, 7, 1):
+        W = 5
+        c2w = torch.eye(4)[:3, :4].clone(); c2w[0, 3] = 0.125
+        got = S.render_sharded(H, W, 10.0, c2w, 64, {}, render_fn=fake_render)
+        ref = fake_render(H, W, 10.0, c2w=c2w, patch=(0, 0, H, W))
+        ok = ok and all(torch.equal(a, b) for a, b in zip(got, ref[:4]))
+    if rank == 0:
+        torch.save({"ok": ok}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_frame_equals_single_process(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "sharded.pt")
+    mp.spawn(_sharded_worker, args=(2, port, out), nprocs=2, join=True)
+    assert torch.load(out)["ok"]

@@ -98,3 +98,18 @@ def test_render_path_frames_dumps_and_patches(tmp_path):
     prgb.sum().backward()
     # rgb of the fine pass reaches the fine network only: the resampled depths are detached (run_nerf.py:700)
     assert float(kw["network_fine"].flat.grad.abs().max()) > 0 and kw["network_fn"].flat.grad is None
+
+
+@pytest.mark.gpu
+def test_render_sharded_single_rank_is_render():
+    import spin_nerf_amd as S
+    from test_gpu_render import build
+    g = load("render_c2w_fine_vd")
+    _, _, kw = build(S, g)
+    H, W, f, chunk = int(g["H"]), int(g["W"]), float(g["focal"]), int(g["chunk"])
+    c2w = T(g["c2w"]).cuda()
+    with torch.no_grad():
+        ref = S.render(H, W, f, chunk=chunk, c2w=c2w[:3, :4], **kw)
+    got = S.render_sharded(H, W, f, c2w, chunk, kw)
+    for a, b in zip(got, ref[:4]):
+        assert torch.equal(a, b)
