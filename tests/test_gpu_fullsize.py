@@ -149,3 +149,28 @@ def test_training_step_at_bench_size(S):
     assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), (losses[:5], losses[-5:])
     for n, b in zip(tr.nets, before):
         assert torch.isfinite(n.flat).all() and float((n.flat.detach() - b).abs().max()) > 0
+
+
+def test_one_launch_beyond_4_gib_of_saved_activations(S):
+    """1 048 576 samples in one launch: 5.7 GB of saved activations and 5.2 GB of d z, i.e. section offsets
+    past 2^32 in the asm stores, the dgrad flag loads and the wgrad DMA addresses.  Must equal the same
+    samples pushed through in four launches (forward bit-exact, gradients up to fp32 summation order)."""
+    _, net = _net(S, 15)
+    n_rays, s = 4096, 256
+    pts, dirs = _inputs(7, n_rays, s)
+    d = torch.randn(n_rays, s, 4, generator=torch.Generator().manual_seed(8)).cuda()
+    lib = S._lib.load()
+    assert lib.snr_mlp_act_bytes(net.cfg, n_rays * s) > 2 ** 32
+    net.flat.grad = None
+    whole = net.query(pts, dirs)
+    whole.backward(d)
+    g_whole = net.flat.grad.clone()
+    net.flat.grad = None
+    parts = []
+    for a in range(0, n_rays, 1024):
+        o = net.query(pts[a:a + 1024], dirs[a:a + 1024])
+        o.backward(d[a:a + 1024])
+        parts.append(o.detach())
+    assert torch.equal(whole.detach(), torch.cat(parts, 0))
+    rel = float((g_whole - net.flat.grad).norm() / g_whole.norm())
+    assert torch.isfinite(g_whole).all() and rel < 1e-5, rel
