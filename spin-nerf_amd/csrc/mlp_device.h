@@ -373,7 +373,10 @@ __device__ __forceinline__ void store16_stream(const char* sbase, uint32_t voff,
   // leading s_nop 4: the base may have been produced by a VALU instruction (v_readlane of a spilled SGPR,
   // v_readfirstlane), which a VMEM instruction may read only 5 wait states later; again the compiler
   // guarantees that only for memory instructions it knows.
-  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 0" ::"v"(voff), "v"(v), "s"(sbase), "n"(OFF));
+#ifndef SNR_STORE_POLICY
+#define SNR_STORE_POLICY "nt"   // A/B builds: "", "sc1", "sc0 sc1", "nt sc1" ...
+#endif
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3 " SNR_STORE_POLICY "\n\ts_nop 0" ::"v"(voff), "v"(v), "s"(sbase), "n"(OFF));
 }
 
 // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section tile (layout [frag][32 samples][32 B], odd frags

@@ -112,6 +112,53 @@ class RenderTrainer:
         mse = img2mse(rgb, target_clf)
         return loss.detach(), -10.0 * torch.log10(mse)
 
+    # ---- checkpoints in the reference's format (run_nerf.py:1626-1636 written, :448-462 read) ----------
+    def state_dict(self):
+        """{'global_step', 'network_fn_state_dict', 'network_fine_state_dict', 'optimizer_state_dict'} with the
+        optimizer state laid out as torch.optim.Adam over the per-layer parameters in `grad_vars` order
+        (coarse net's parameters, then the fine net's: run_nerf.py:398-425) — loadable by the reference."""
+        fn, fine = self.kw.get('network_fn'), self.kw.get('network_fine')
+        state, idx = {}, 0
+        for n, m, v in zip(self.nets, self.m, self.v):
+            for (k, mv), vv in zip(n.named_views(m).items(), n.named_views(v).values()):
+                state[idx] = {'step': torch.tensor(float(self.global_step)), 'exp_avg': mv.detach().clone(),
+                              'exp_avg_sq': vv.detach().clone()}
+                idx += 1
+        group = {'lr': self.current_lr(), 'betas': (0.9, 0.999), 'eps': 1e-8, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'params': list(range(idx))}
+        return {'global_step': self.global_step,
+                'network_fn_state_dict': fn.state_dict() if fn is not None else None,
+                'network_fine_state_dict': fine.state_dict() if fine is not None else None,
+                'optimizer_state_dict': {'state': state if self.global_step > 0 else {}, 'param_groups': [group]}}
+
+    def save_checkpoint(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load_state_dict(self, ckpt):
+        """Accepts checkpoints written by save_checkpoint() or by the reference's train()."""
+        fn, fine = self.kw.get('network_fn'), self.kw.get('network_fine')
+        if fn is not None:
+            fn.load_state_dict(ckpt['network_fn_state_dict'])
+        if fine is not None and ckpt.get('network_fine_state_dict') is not None:
+            fine.load_state_dict(ckpt['network_fine_state_dict'])
+        self.global_step = int(ckpt['global_step'])
+        st = ckpt['optimizer_state_dict']['state']
+        idx = 0
+        for n, m, v in zip(self.nets, self.m, self.v):
+            for mv, vv in zip(n.named_views(m).values(), n.named_views(v).values()):
+                if idx in st:
+                    mv.copy_(st[idx]['exp_avg'].reshape(mv.shape))
+                    vv.copy_(st[idx]['exp_avg_sq'].reshape(vv.shape))
+                else:
+                    mv.zero_(); vv.zero_()
+                idx += 1
+        for n in self.nets:
+            n.mark_weights_changed()
+
+    def load_checkpoint(self, path, map_location=None):
+        self.load_state_dict(torch.load(path, map_location=map_location, weights_only=False))
+
     def apply_gradients(self):
         if self.world_size > 1:
             import torch.distributed as dist
