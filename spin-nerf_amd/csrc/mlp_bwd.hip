@@ -297,3 +297,12 @@ extern "C" int snr_mlp_backward(const snr_mlp_config* c, const void* packed, con
   return c->precision == SNR_PREC_BF16 ? backward_impl<kBF16>(c, packed, d_raw, n, act, ws, grad, accumulate, s)
                                        : backward_impl<kFP32>(c, packed, d_raw, n, act, ws, grad, accumulate, s);
 }
+
+#ifdef SNR_TIMING
+extern "C" int snr_debug_read(unsigned long long* out8) {
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(snr::g_snr_dbg), 8 * sizeof(unsigned long long));
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(snr::g_snr_dbg), z, sizeof(z));
+  return (int)e;
+}
+#endif

@@ -40,9 +40,10 @@ template <int P> __device__ __forceinline__ int act_row(int j, int f) {
 #ifndef SNR_ABLATE
 #define SNR_ABLATE 0   // bit mask of timing experiments (results are garbage): see Pipe
 #endif
-constexpr int kBlockFrags = 16;
-constexpr int kRing = 6;
-constexpr int kDepth = 4;    // = kRing - 2: the slot re-filled on entering block b is that of block b-2
+// kBlockFrags (mlp_layout.h) fragments per block; ring slots and blocks in flight are chosen so that the bytes in
+// flight stay 64 KiB: 16-fragment blocks -> 6 slots, 4 ahead; 32-fragment blocks (A/B builds) -> 4 slots, 2 ahead
+constexpr int kRing = kBlockFrags == 16 ? 6 : 4;
+constexpr int kDepth = kRing - 2;    // the slot re-filled on entering block b is that of block b-2
 constexpr int kRingBytes = kRing * kBlockFrags * 1024;
 
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
@@ -55,6 +56,11 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
+
+#ifdef SNR_TIMING   // instrumentation build: s_memtime around the block waits (tests/probes/fwd_ablate.py prints it)
+static __device__ unsigned long long g_snr_dbg[8];   // wait, barrier, (unused), acquires, kernel, waves
+#define SNR_T() __builtin_readcyclecounter()
+#endif
 
 template <int P, int WAVES_> struct Pipe {
   using M = Mma<P>;
@@ -71,6 +77,9 @@ template <int P, int WAVES_> struct Pipe {
   uint32_t lane_off;  // lane * 16
   uint32_t ring_base; // LDS byte address of this lane's 16 B in fragment 0 of slot 0
   uint32_t cur_base;  // ... of the slot being consumed
+#ifdef SNR_TIMING
+  unsigned long long t_wait = 0, t_bar = 0, n_acq = 0, t_start = 0;
+#endif
   int pend;          // DMA pieces of the block being issued that are still to be issued
   const char* pend_src;
   char* pend_dst;
@@ -78,6 +87,9 @@ template <int P, int WAVES_> struct Pipe {
   __device__ __forceinline__ void init(char* ring_, const char* gbase_, int n_blocks_, int wave_, int lane_) {
     ring = ring_; gbase = gbase_; n_blocks = n_blocks_; wave = wave_; lane = lane_;
     issue_blk = 0; issue_slot = 0; cur_slot = kRing - 1; pend = 0;
+#ifdef SNR_TIMING
+    t_start = SNR_T();
+#endif
     lane_off = (uint32_t)lane_ * 16u;
     ring_base = lds_addr(ring_) + lane_off; cur_base = ring_base;
     for (int d = 0; d < kDepth; ++d) { begin_issue(); flush(); }
@@ -120,20 +132,37 @@ template <int P, int WAVES_> struct Pipe {
 #endif
     flush();   // the counted wait below assumes every older block is completely issued
     // allowed outstanding = this wave's pieces of the kDepth-1 younger blocks
-    static_assert(PIECES * (kDepth - 1) == 6 || PIECES * (kDepth - 1) == 12, "add the immediate");
-#if SNR_ABLATE & 16   // timing experiment (racy): tolerate 24 more outstanding operations (stores)
-    if constexpr (PIECES * (kDepth - 1) == 6) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
-    else
+#ifdef SNR_TIMING
+    const unsigned long long t0 = SNR_T();
 #endif
-    if constexpr (PIECES * (kDepth - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#if SNR_ABLATE & 16   // timing experiment (racy): tolerate 24 more outstanding operations (stores)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (kDepth - 1) + 24) : "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (kDepth - 1)) : "memory");
+#endif
+#ifdef SNR_TIMING
+    const unsigned long long t1 = SNR_T();
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef SNR_TIMING
+    const unsigned long long t2 = SNR_T();
+    t_wait += t1 - t0; t_bar += t2 - t1; ++n_acq;
+#endif
     cur_slot = cur_slot + 1 == kRing ? 0 : cur_slot + 1;
     begin_issue();   // pieces follow from the MFMA loop (issue_one)
   }
 
-  __device__ __forceinline__ void drain() { flush(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  __device__ __forceinline__ void drain() {
+    flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SNR_TIMING
+    if (lane == 0) {
+      atomicAdd(&g_snr_dbg[0], t_wait); atomicAdd(&g_snr_dbg[1], t_bar); atomicAdd(&g_snr_dbg[3], n_acq);
+      atomicAdd(&g_snr_dbg[4], SNR_T() - t_start); atomicAdd(&g_snr_dbg[5], 1ull);
+    }
+#endif
+  }
 
   // ---- LDS reads the compiler must not see ----------------------------------------------------
   // The AMDGPU backend orders every LDS access it knows about behind ALL outstanding LDS-DMA loads

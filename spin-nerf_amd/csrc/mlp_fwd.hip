@@ -453,3 +453,12 @@ extern "C" int snr_mlp_forward(const snr_mlp_config* c, const void* packed, cons
   return bf ? SNR_FWD(kBF16) : SNR_FWD(kFP32);
 #undef SNR_FWD
 }
+
+#ifdef SNR_TIMING
+extern "C" int snr_debug_read_fwd(unsigned long long* out8) {
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(snr::g_snr_dbg), 8 * sizeof(unsigned long long));
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(snr::g_snr_dbg), z, sizeof(z));
+  return (int)e;
+}
+#endif

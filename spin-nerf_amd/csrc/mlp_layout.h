@@ -41,6 +41,12 @@ constexpr int kTileSamples = 32;
 
 enum Precision { kBF16 = 0, kFP32 = 1 };
 
+// fragments (1 KiB each) per DMA block of the packed weight stream; every stage starts on a block boundary
+#ifndef SNR_BLOCK_FRAGS
+#define SNR_BLOCK_FRAGS 16   // A/B builds: 32
+#endif
+constexpr int kBlockFrags = SNR_BLOCK_FRAGS;
+
 template <int P> struct Prec;
 template <> struct Prec<kBF16> { static constexpr int EPF = 8, FPT = 2, ESZ = 2; };
 template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4; };

@@ -53,7 +53,7 @@ inline PackTable make_pack_table(int multires, int multires_views, int use_viewd
   T.multires = identity ? 0 : multires;
   T.multires_views = identity ? 0 : multires_views;
   int frag = 0, n = 0;
-  constexpr int BF = 16;  // kBlockFrags: every entry (= stage) starts on a DMA block boundary
+  constexpr int BF = kBlockFrags;  // every entry (= stage) starts on a DMA block boundary
   auto add = [&](int tiles, int transposed, int rows_valid, PackSrc a, PackSrc b) {
     frag = (frag + BF - 1) / BF * BF;
     PackEntry& E = T.e[n++];
