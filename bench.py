@@ -112,12 +112,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    # test hooks (a gpurun box has ONE GPU and RCCL refuses two ranks on one device): SNR_BENCH_SAME_DEVICE=1 puts
+    # every rank on cuda:0 and SNR_BENCH_BACKEND=gloo swaps the collective backend, so that the world>1 code path
+    # of this file and of the trainer can be exercised there.  The driver's runs use neither.
+    if os.environ.get("SNR_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("SNR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if ns.gpus != world and rank == 0:
         print(f"warning: --gpus {ns.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
