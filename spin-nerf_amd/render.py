@@ -102,6 +102,24 @@ def render_rays(ray_batch,
     viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 9 else None      # run_nerf.py:642
     near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
 
+    # The chunk's uniform draws (stratified offsets + inverse-CDF positions) and normal draws (density noise of
+    # both passes) come from one generator launch each instead of four: same distributions, contiguous slices.
+    if not pytest and not randoms:
+        randoms = {}
+        if perturb > 0.:
+            uni = torch.rand(N_rays * (N_samples + N_importance), device=dev)
+            randoms["t_rand"] = uni[:N_rays * N_samples].view(N_rays, N_samples)
+            if N_importance > 0:
+                randoms["u"] = uni[N_rays * N_samples:].view(N_rays, N_importance)
+        if raw_noise_std > 0.:
+            S_f = N_samples + N_importance
+            nrm = torch.randn(N_rays * (N_samples + (S_f if N_importance > 0 else 0)), device=dev)
+            if raw_noise_std != 1.:
+                nrm = nrm * raw_noise_std
+            randoms["noise_c"] = nrm[:N_rays * N_samples].view(N_rays, N_samples)
+            if N_importance > 0:
+                randoms["noise_f"] = nrm[N_rays * N_samples:].view(N_rays, S_f)
+
     # stratified samples (run_nerf.py:646-668)
     t_rand = None
     if perturb > 0.:
