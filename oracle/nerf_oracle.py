@@ -298,6 +298,16 @@ def raw2outputs(raw, z_vals, rays_d, noise=None, white_bkgd=False, need_alpha=Fa
 # the reference's pytest=True random hook
 # --------------------------------------------------------------------------
 
+def raw2outputs_mvseg(raw, z_vals, rays_d, noise=None, white_bkgd=False):
+    """MVSeg variant (MVSeg/DS_NeRF/run_nerf_helpers.py:350-413, default path: no only_object): raw carries a 5th
+    channel of per-sample logits, composited with DETACHED weights: prob_map = sum(w.detach() * logit) (:405).
+    Returns (rgb_map, disp_map, acc_map, weights, depth_map, prob_map, logits)."""
+    rgb_map, disp_map, acc_map, weights, depth_map, _ = raw2outputs(raw, z_vals, rays_d, noise, white_bkgd)
+    logits = raw[..., 4]
+    prob_map = torch.sum(weights.detach() * logits, -1)
+    return rgb_map, disp_map, acc_map, weights, depth_map, prob_map, logits
+
+
 def pytest_randoms(N_rays, N_samples, N_importance, perturb, raw_noise_std, dtype=torch.float32):
     """The numbers the reference draws under ``pytest=True``: each site re-seeds numpy
     with 0 and draws ``np.random.rand`` (run_nerf.py:663-666, helpers:319-327, 377-380 —

@@ -106,6 +106,21 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=F
     return rgb, disp, acc, w, depth, alpha
 
 
+def raw2outputs_mvseg(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, noise=None, rays=None):
+    """MVSeg's 5-channel variant (MVSeg/DS_NeRF/run_nerf_helpers.py:350-413, default path — `only_object` and its
+    alpha post-processing are not built): the compositing kernel handles channels 0..3 and
+    zeroes the gradient of channel 4; the logit channel is composited with the DETACHED weights
+    (`prob_map = sum(w.detach() * logit)`, :405), so its gradient reaches raw[..., 4] only.
+    Returns (rgb_map, disp_map, acc_map, weights, depth_map, prob_map, logits)."""
+    if raw.shape[-1] < 5:
+        raise ValueError("raw2outputs_mvseg needs 5 raw channels (rgb, sigma, logit)")
+    rgb, disp, acc, w, depth, _ = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd, pytest, noise=noise,
+                                              rays=rays)
+    logits = raw[..., 4]
+    prob = torch.sum(w.detach() * logits, -1)
+    return rgb, disp, acc, w, depth, prob, logits
+
+
 # ----------------------------------------------------------------------------------------------
 # rays (helpers:249-300)
 # ----------------------------------------------------------------------------------------------
