@@ -65,3 +65,18 @@ def test_built_listings_are_clean():
         assert chk.check(p) == 0, p
         txt = open(p).read()
         assert "ds_read_b128" in txt   # the listing really contains the asm reads
+
+
+def test_checker_covers_asm_global_loads(tmp_path):
+    load = """
+        ;;#ASMSTART
+        s_nop 4
+        global_load_dwordx4 v[0:3], v8, s[2:3]
+        ;;#ASMEND
+    """
+    dma = "        global_load_lds_dwordx4 v9, s[4:5]\n"
+    use = "        v_and_b32_e32 v20, 0x10001, v1\n"
+    wait = "        ;;#ASMSTART\n        s_waitcnt vmcnt(6)\n        ;;#ASMEND\n"
+    assert chk.check(_listing(tmp_path, load + use)) == 1                       # consumed right away
+    assert chk.check(_listing(tmp_path, load + dma * 3 + wait + use)) == 1      # only 3 loads behind it: vmcnt(6) proves nothing
+    assert chk.check(_listing(tmp_path, load + dma * 7 + wait + use)) == 0      # 7 younger loads, at most 6 outstanding

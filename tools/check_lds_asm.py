@@ -24,10 +24,11 @@ def regs(text):
 def check(path):
     bad = 0
     kernel, pending, issued, in_asm = None, [], 0, False
+    vpending = []   # asm global loads: [destination registers, line, vector-memory LOADS issued behind it]
     for ln, line in enumerate(open(path), 1):
         s = line.strip()
         if s.endswith(":") and s.startswith("_Z"):
-            kernel, pending, issued = s[:-1], [], 0
+            kernel, pending, issued, vpending = s[:-1], [], 0, []
             continue
         if s.startswith(";;#ASMSTART"):
             in_asm = True; continue
@@ -41,17 +42,35 @@ def check(path):
             issued += 1
             pending.append((issued, dst, ln))
             continue
+        # asm global loads (dgrad's ReLU flags): loads retire in order, so one is complete once a
+        # `s_waitcnt vmcnt(N)` executes with at least N loads issued behind it (stores sharing the counter
+        # only make the wait stricter)
+        if code.startswith(("global_load", "buffer_load", "scratch_load")):
+            for v in vpending:
+                v[2] += 1
+            if in_asm and not code.startswith("global_load_lds"):
+                vpending.append([regs(code.split(",")[0]), ln, 0])
+                continue
         m = re.match(r"s_waitcnt\s+(.*)", code)
         if m:
             lg = re.search(r"lgkmcnt\((\d+)\)", m.group(1))
             if lg:
                 n = int(lg.group(1))
                 pending = [p for p in pending if issued - p[0] < n]   # younger than the n most recent stay
+            vm = re.search(r"vmcnt\((\d+)\)", m.group(1))
+            if vm:
+                n = int(vm.group(1))
+                vpending = [v for v in vpending if v[2] < n]
             continue
         if code.startswith("s_endpgm"):
-            pending = []
+            pending, vpending = [], []
             continue
         touched = regs(code)
+        for dst, l0, _ in vpending:
+            if touched & dst:
+                print(f"{path}:{ln}: {kernel[:60]}: `{code.strip()}` touches the destination of the global load at line {l0} before a wait covers it")
+                bad += 1
+                break
         for seq, dst, l0 in pending:
             if touched & dst:
                 print(f"{path}:{ln}: {kernel[:60]}: `{code.strip()}` touches the destination of the LDS read at line {l0} before its wait")
