@@ -279,7 +279,7 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   }
   st = launch_status();
   if (st != SNR_OK) return st;
-  const int per_job = 256 * 257;
+  const int per_job = 256 * (256 / 4 + 1);   // rows x (4-column groups + the bias thread)
   {
     ProfScope ps(K_MLP_WGRAD_REDUCE, s);
     mlp_wgrad_reduce_kernel<P><<<dim3((per_job + 255) / 256, (unsigned)w.n_jobs), dim3(256), 0, s>>>(w, grad, accumulate);

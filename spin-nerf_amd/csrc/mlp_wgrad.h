@@ -344,37 +344,43 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, i
   // Every parameter element a job produces is produced by exactly one (job, row, column): without
   // `accumulate` the result is stored, not added, and the gradient buffer needs no clearing first
   // (tests/test_gpu_kernels.py: test_mlp_backward_overwrites_every_element).
-  // blockIdx.y = job; threads cover (row, col) plus one extra column (col == NB) for the bias
+  // blockIdx.y = job; a thread covers (row, 4 consecutive partial-sum columns); one extra thread per row does
+  // the bias.  16-byte loads, two independent accumulators per element.
   const WgradJob& J = a.job[blockIdx.y];
-  const int NA = J.nta * 32, NB = J.ntb * 32;
+  const int NA = J.nta * 32, NB = J.ntb * 32, NQ = NB / 4;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)NA * (NB + 1)) return;
-  const int ra = (int)(idx / (NB + 1)), cb = (int)(idx % (NB + 1));
+  if (idx >= (int64_t)NA * (NQ + 1)) return;
+  const int ra = (int)(idx / (NQ + 1)), q = (int)(idx % (NQ + 1));
   if (ra >= J.a_ks * 2 * Prec<P>::EPF) return;
   const int n = slot_true_index<P>(J.a_kind, ra, 0) - (J.a_kind == SRC_OUT ? J.row_off : 0);
   if (n < 0 || n >= J.rows_valid) return;
-  if (cb == NB) {
+  if (q == NQ) {
     if (J.bias_off < 0) return;
     float s = 0.f;
     for (int sp = 0; sp < J.n_splits; ++sp) s += a.part[J.bias_part_off + (int64_t)sp * NA + ra];
     grad[J.bias_off + n] = accumulate ? grad[J.bias_off + n] + s : s;
     return;
   }
+  const int cb = 4 * q;
   if (cb >= J.b_ks * 2 * Prec<P>::EPF) return;
-  const int k = slot_true_index<P>(J.b_kind, cb, J.b_kind == SRC_ENC_DIR ? a.L_dir : a.L_pts);
-  if (k < 0 || k >= J.cols_valid) return;
-  // four independent partial sums: the loads of a thread are otherwise issued one round trip at a time
   const float* p = a.part + J.part_off + (int64_t)ra * NB + cb;
   const int64_t st = (int64_t)NA * NB;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   int sp = 0;
-  for (; sp + 4 <= J.n_splits; sp += 4) {
-    s0 += p[(sp + 0) * st]; s1 += p[(sp + 1) * st]; s2 += p[(sp + 2) * st]; s3 += p[(sp + 3) * st];
+  for (; sp + 2 <= J.n_splits; sp += 2) {
+    s0 += *(const f32x4*)(p + (sp + 0) * st);
+    s1 += *(const f32x4*)(p + (sp + 1) * st);
   }
-  for (; sp < J.n_splits; ++sp) s0 += p[sp * st];
-  float* g = grad + J.w_off + (int64_t)n * J.ld + J.col_off + k;
-  const float s = (s0 + s1) + (s2 + s3);
-  *g = accumulate ? *g + s : s;
+  if (sp < J.n_splits) s0 += *(const f32x4*)(p + sp * st);
+  const f32x4 s = s0 + s1;
+  float* grow = grad + J.w_off + (int64_t)n * J.ld + J.col_off;
+  const int L = J.b_kind == SRC_ENC_DIR ? a.L_dir : a.L_pts;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = slot_true_index<P>(J.b_kind, cb + e, L);
+    if (k < 0 || k >= J.cols_valid) continue;
+    grow[k] = accumulate ? grow[k] + s[e] : s[e];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
