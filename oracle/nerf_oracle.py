@@ -139,6 +139,25 @@ def nerf_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, input_ch=63, inpu
     return F.linear(h, sd["output_linear.weight"], sd["output_linear.bias"])
 
 
+def nerf_rgb_forward(sd: Dict[str, torch.Tensor], sd_alpha: Dict[str, torch.Tensor], x: torch.Tensor, input_ch=63,
+                     input_ch_views=27, skips=(4,)) -> torch.Tensor:
+    """NeRF_RGB.forward with view directions (helpers:191-216): the trunk, feature/views/rgb heads of ``sd`` (which
+    has no alpha_linear) and the density of the frozen ``sd_alpha`` network evaluated under no_grad (:202-203)."""
+    input_pts, input_views = torch.split(x, [input_ch, input_ch_views], dim=-1)
+    h = input_pts
+    for i in range(8):
+        h = torch.relu(torch.nn.functional.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"]))
+        if i in skips:
+            h = torch.cat([input_pts, h], -1)
+    with torch.no_grad():
+        alpha = nerf_forward(sd_alpha, x, input_ch, input_ch_views, skips, True)[..., 3][..., None]
+    feature = torch.nn.functional.linear(h, sd["feature_linear.weight"], sd["feature_linear.bias"])
+    h = torch.cat([feature, input_views], -1)
+    h = torch.relu(torch.nn.functional.linear(h, sd["views_linears.0.weight"], sd["views_linears.0.bias"]))
+    rgb = torch.nn.functional.linear(h, sd["rgb_linear.weight"], sd["rgb_linear.bias"])
+    return torch.cat([rgb, alpha], -1)
+
+
 def _bf16(t: torch.Tensor) -> torch.Tensor:
     """Round-to-nearest-even to bfloat16 and back (what v_cvt_pk_bf16_f32 does)."""
     return t.to(torch.bfloat16).to(torch.float32)

@@ -8,7 +8,7 @@ The directory name carries a hyphen (it mirrors the reference repo's name), so i
 """
 from . import _lib
 from ._lib import HipLibraryError, LIB_PATH
-from .nerf import NeRF
+from .nerf import NeRF, NeRF_RGB
 from .ops import raw2outputs, raw2outputs_mvseg, sample_coarse, sample_fine, make_rays, mlp_query, adam_step_
 from .render import (render, render_rays, batchify_rays, batchify, run_network, create_nerf, get_embedder, get_rays,
                      ndc_rays, Embedder)
@@ -17,6 +17,6 @@ from .path import render_path, render_sharded, to8b, write_png
 img2mse = lambda x, y: ((x - y) ** 2).mean()                      # helpers:15
 mse2psnr = lambda x: -10. * x.log() / 2.302585092994046           # helpers:17
 
-__all__ = ["NeRF", "render", "render_rays", "batchify_rays", "batchify", "run_network", "create_nerf",
+__all__ = ["NeRF", "NeRF_RGB", "render", "render_rays", "batchify_rays", "batchify", "run_network", "create_nerf",
            "get_embedder", "get_rays", "ndc_rays", "raw2outputs", "raw2outputs_mvseg", "sample_coarse", "sample_fine", "make_rays",
            "mlp_query", "adam_step_", "img2mse", "mse2psnr", "HipLibraryError", "LIB_PATH", "Embedder", "render_path", "render_sharded", "to8b", "write_png"]

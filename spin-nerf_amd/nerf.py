@@ -183,3 +183,71 @@ class NeRF(nn.Module):
         dirs = x2[:, self.input_ch:self.input_ch + 3] if self.use_viewdirs else None
         raw = mlp_query(self, pts=x2[:, :3], viewdirs=dirs, samples_per_ray=1)
         return raw.reshape(list(lead) + [raw.shape[-1]])
+
+
+class NeRF_RGB(NeRF):
+    """Colour network whose density comes from a frozen, separately trained network (helpers:159-216): same
+    trunk as NeRF, no `alpha_linear`; with view directions the output is cat(rgb, alpha_model(x)[..., 3]) with
+    the density evaluated under no_grad (:202-203), without them it is `output_linear(h)` as in NeRF.
+
+    The fused kernels evaluate a full NeRF, so the flat buffer keeps an `alpha_linear` block that stays zero
+    (its output is replaced, hence its gradient is zero and Adam never moves it); the state dict follows the
+    reference: no `alpha_linear.*`, and the `alpha_model.*` entries of the registered sub-module."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False,
+                 alpha_model=None, precision=None):
+        super().__init__(D=D, W=W, input_ch=input_ch, input_ch_views=input_ch_views, output_ch=output_ch, skips=skips,
+                         use_viewdirs=use_viewdirs, precision=precision)
+        if self.use_viewdirs:
+            with torch.no_grad():
+                v = self.named_views(self.flat)
+                v["alpha_linear.weight"].zero_()
+                v["alpha_linear.bias"].zero_()
+        self.alpha_model = alpha_model
+
+    def _own_views(self, flat):
+        return OrderedDict((k, v) for k, v in self.named_views(flat).items() if not k.startswith("alpha_linear."))
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        for k, v in self._own_views(self.flat if keep_vars else self.flat.detach()).items():
+            destination[prefix + k] = v if keep_vars else v.clone()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        views = self._own_views(self.flat.detach())
+        for k, v in views.items():
+            key = prefix + k
+            if key not in state_dict:
+                if strict:
+                    missing_keys.append(key)
+                continue
+            if tuple(state_dict[key].shape) != tuple(v.shape):
+                error_msgs.append(f"size mismatch for {key}")
+                continue
+            with torch.no_grad():
+                v.copy_(state_dict[key])
+        if strict:
+            for key in state_dict:
+                rest = key[len(prefix):]
+                if key.startswith(prefix) and rest not in views and not rest.startswith("alpha_model."):
+                    unexpected_keys.append(key)
+        self._packed_key = None
+
+    def _with_density(self, raw, density_fn):
+        if not self.use_viewdirs:
+            return raw
+        if self.alpha_model is None:
+            raise RuntimeError("NeRF_RGB with view directions needs an alpha_model (helpers:202-203)")
+        with torch.no_grad():
+            alpha = density_fn(self.alpha_model)[..., 3:4]
+        return torch.cat([raw[..., :3], alpha], -1)
+
+    def query(self, inputs, viewdirs=None):
+        return self._with_density(super().query(inputs, viewdirs), lambda m: m.query(inputs, viewdirs))
+
+    def query_rays(self, ray_batch, z_vals, viewdirs=None):
+        return self._with_density(super().query_rays(ray_batch, z_vals, viewdirs),
+                                  lambda m: m.query_rays(ray_batch, z_vals, viewdirs))
+
+    def forward(self, x):
+        return self._with_density(super().forward(x), lambda m: m(x))

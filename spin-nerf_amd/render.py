@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .nerf import NeRF
+from .nerf import NeRF, NeRF_RGB
 
 DEBUG = False
 
@@ -316,16 +316,29 @@ def create_nerf(args, device=None):
         embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
     output_ch = 5 if args.N_importance > 0 else 4
     skips = [4]
-    if getattr(args, "alpha_model_path", None) is not None:
-        raise NotImplementedError("--alpha_model_path (NeRF_RGB, helpers:159-216) is outside the HIP path's scope")
-    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
-                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, precision=precision).to(device)
-    grad_vars = list(model.parameters())
+    mk = dict(input_ch=input_ch, output_ch=output_ch, skips=skips, input_ch_views=input_ch_views,
+              use_viewdirs=args.use_viewdirs, precision=precision)
+    alpha_model = None
+    if getattr(args, "alpha_model_path", None) is None:
+        model = NeRF(D=args.netdepth, W=args.netwidth, **mk).to(device)
+        grad_vars = list(model.parameters())
+    else:
+        # density from a frozen, separately trained fine network (run_nerf.py:395-412)
+        alpha_model = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, **mk).to(device)
+        print('Alpha model reloading from', args.alpha_model_path)
+        ckpt = torch.load(args.alpha_model_path, map_location=device, weights_only=False)
+        alpha_model.load_state_dict(ckpt['network_fine_state_dict'])
+        if not getattr(args, "no_coarse", False):
+            model = NeRF_RGB(D=args.netdepth, W=args.netwidth, alpha_model=alpha_model, **mk).to(device)
+            grad_vars = list(model.parameters())
+        else:
+            model, grad_vars = None, []
     model_fine = None
     if args.N_importance > 0:
-        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
-                          skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs,
-                          precision=precision).to(device)
+        if alpha_model is None:
+            model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, **mk).to(device)
+        else:
+            model_fine = NeRF_RGB(D=args.netdepth_fine, W=args.netwidth_fine, alpha_model=alpha_model, **mk).to(device)
         grad_vars += list(model_fine.parameters())
 
     def network_query_fn(inputs, viewdirs, network_fn):
@@ -353,7 +366,8 @@ def create_nerf(args, device=None):
         except (ValueError, KeyError):
             # a reference checkpoint stores per-layer Adam moments; this build keeps one flat buffer
             print('optimizer state of a per-layer checkpoint not restored (flat-parameter layout)')
-        model.load_state_dict(ckpt['network_fn_state_dict'])
+        if model is not None:
+            model.load_state_dict(ckpt['network_fn_state_dict'])
         if model_fine is not None:
             model_fine.load_state_dict(ckpt['network_fine_state_dict'])
 

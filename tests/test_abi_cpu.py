@@ -113,3 +113,28 @@ def test_embedder_and_create_nerf_contract(S, tmp_path):
     args.no_reload = False
     _, _, start2, _, _ = S.create_nerf(args, device=torch.device("cpu"))
     assert start2 == 7
+
+
+def test_create_nerf_with_alpha_model_path(S, tmp_path):
+    """--alpha_model_path (run_nerf.py:395-425): a frozen density network loaded from a checkpoint's
+    network_fine_state_dict, NeRF_RGB colour networks for coarse and fine that share it."""
+    import argparse
+    torch.manual_seed(0)
+    donor = S.NeRF(input_ch=63, input_ch_views=27, output_ch=5, use_viewdirs=True)
+    torch.save({"network_fine_state_dict": donor.state_dict()}, tmp_path / "alpha.tar")
+    (tmp_path / "run").mkdir()
+    args = argparse.Namespace(multires=10, multires_views=4, i_embed=0, use_viewdirs=True, N_importance=128,
+                              N_samples=64, alpha_model_path=str(tmp_path / "alpha.tar"), netdepth=8, netwidth=256,
+                              netdepth_fine=8, netwidth_fine=256, netchunk=65536, lrate=5e-4, basedir=str(tmp_path),
+                              expname="run", ft_path=None, no_reload=True, perturb=1.0, white_bkgd=True,
+                              raw_noise_std=1.0, dataset_type="llff", no_ndc=True, lindisp=True, sigma_loss=False,
+                              no_coarse=False)
+    kw_train, _, _, grad_vars, _ = S.create_nerf(args, device=torch.device("cpu"))
+    c, f = kw_train["network_fn"], kw_train["network_fine"]
+    assert isinstance(c, S.NeRF_RGB) and isinstance(f, S.NeRF_RGB) and c.alpha_model is f.alpha_model
+    assert torch.equal(c.alpha_model.flat.detach(), donor.flat.detach())
+    # like the reference, the (shared) density network's parameters ride along in both modules' parameter lists
+    assert len(grad_vars) == 4 and "alpha_linear.weight" not in c.state_dict() and "alpha_model.alpha_linear.weight" in c.state_dict()
+    args.no_coarse = True
+    kw_train, _, _, grad_vars, _ = S.create_nerf(args, device=torch.device("cpu"))
+    assert kw_train["network_fn"] is None and len(grad_vars) == 2
