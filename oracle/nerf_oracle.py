@@ -327,6 +327,23 @@ def raw2outputs_mvseg(raw, z_vals, rays_d, noise=None, white_bkgd=False):
     return rgb_map, disp_map, acc_map, weights, depth_map, prob_map, logits
 
 
+def sigma_loss(sd, rays_o, rays_d, viewdirs, near, depths, N_samples, perturb=0., t_rand=None, noise=None):
+    """SigmaLoss.calculate_loss (DS_NeRF/loss.py:15-44): samples between near and the known depth, stratified
+    perturbation, sigma = relu(raw[...,3] + noise), loss = -exp(sigma_last) / (sum exp(sigma) + 1) per ray."""
+    N_rays = rays_o.shape[0]
+    t_vals = torch.linspace(0., 1., steps=N_samples).expand([N_rays, N_samples])
+    z_vals = near * (1. - t_vals) + depths[:, None] * t_vals
+    if perturb > 0.:
+        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        upper = torch.cat([mids, z_vals[..., -1:]], -1)
+        lower = torch.cat([z_vals[..., :1], mids], -1)
+        z_vals = lower + (upper - lower) * t_rand
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    raw = run_network(sd, pts, viewdirs)
+    sigma = F.relu(raw[..., 3] + (noise if noise is not None else 0.))
+    return -torch.exp(sigma[:, -1]) / (torch.sum(torch.exp(sigma), dim=1) + 1)
+
+
 def pytest_randoms(N_rays, N_samples, N_importance, perturb, raw_noise_std, dtype=torch.float32):
     """The numbers the reference draws under ``pytest=True``: each site re-seeds numpy
     with 0 and draws ``np.random.rand`` (run_nerf.py:663-666, helpers:319-327, 377-380 —

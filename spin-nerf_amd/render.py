@@ -391,6 +391,7 @@ def create_nerf(args, device=None):
     render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
     render_kwargs_test['perturb'] = False
     render_kwargs_test['raw_noise_std'] = 0.
-    if getattr(args, "sigma_loss", False):
-        raise NotImplementedError("--sigma_loss (loss.py:8-44) is outside the HIP path's scope (off in every config)")
+    if getattr(args, "sigma_loss", False):                                 # run_nerf.py:490-492
+        from .loss import SigmaLoss
+        render_kwargs_train['sigma_loss'] = SigmaLoss(args.N_samples, args.perturb, args.raw_noise_std)
     return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
