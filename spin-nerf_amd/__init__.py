@@ -13,11 +13,12 @@ from .ops import raw2outputs, raw2outputs_mvseg, sample_coarse, sample_fine, mak
 from .render import (render, render_rays, batchify_rays, batchify, run_network, create_nerf, get_embedder, get_rays,
                      ndc_rays, Embedder)
 from .loss import SigmaLoss
-from .path import render_path, render_sharded, to8b, write_png
+from .path import (render_path, render_sharded, render_path_projection, render_test_ray, sample_sigma, convert_pose,
+                   to8b, write_png)
 
 img2mse = lambda x, y: ((x - y) ** 2).mean()                      # helpers:15
 mse2psnr = lambda x: -10. * x.log() / 2.302585092994046           # helpers:17
 
 __all__ = ["NeRF", "NeRF_RGB", "render", "render_rays", "batchify_rays", "batchify", "run_network", "create_nerf",
            "get_embedder", "get_rays", "ndc_rays", "raw2outputs", "raw2outputs_mvseg", "sample_coarse", "sample_fine", "make_rays",
-           "mlp_query", "adam_step_", "img2mse", "mse2psnr", "HipLibraryError", "LIB_PATH", "Embedder", "SigmaLoss", "render_path", "render_sharded", "to8b", "write_png"]
+           "mlp_query", "adam_step_", "img2mse", "mse2psnr", "HipLibraryError", "LIB_PATH", "Embedder", "SigmaLoss", "render_path", "render_sharded", "render_path_projection", "render_test_ray", "sample_sigma", "convert_pose", "to8b", "write_png"]

@@ -141,3 +141,60 @@ def render_sharded(H, W, focal, c2w, chunk, render_kwargs, group=None, render_fn
     else:
         frame = band[:H]
     return [frame[..., 0:3], frame[..., 3], frame[..., 4], frame[..., 5]]
+
+
+def convert_pose(C2W):
+    """run_nerf.py:342-347: flip the y and z axes of a 4x4 camera-to-world matrix (OpenGL <-> OpenCV)."""
+    flip_yz = np.eye(4)
+    flip_yz[1, 1] = -1
+    flip_yz[2, 2] = -1
+    return np.matmul(C2W, flip_yz)
+
+
+def render_path_projection(render_poses, hwf, chunk, render_kwargs, render_factor=0):
+    """run_nerf.py:310-339: per pose the fine pass's sample depths and weights (numpy) plus the converted pose and
+    the intrinsics — the inputs of the mask-projection tooling."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    K = np.array([[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]])
+    z_vals, weights, c2ws = [], [], []
+    for i, c2w in enumerate(render_poses):
+        with torch.no_grad():
+            _, _, _, _, extras = render(H, W, focal, chunk=chunk, c2w=c2w[:3, :4], retraw=True, **render_kwargs)
+        z_vals.append(_np(extras['z_vals']))
+        weights.append(_np(extras['weights']))
+        c2ws.append(convert_pose(np.concatenate([_np(render_poses[i])[:3, :4], np.array([[0, 0, 0, 1]])], axis=0)))
+    return z_vals, weights, c2ws, K
+
+
+def sample_sigma(rays_o, rays_d, viewdirs, network, z_vals, network_query):
+    """run_nerf_helpers.py:404-417: colour and density along given depths plus the composited depth.  (The
+    reference unpacks five values from its six-valued raw2outputs there and cannot run as written; this returns
+    what it means to: rgb [N,S,3], sigma [N,S], depth_map [N].)"""
+    from .ops import raw2outputs
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    raw = network_query(pts, viewdirs, network)
+    rgb = torch.sigmoid(raw[..., :3])
+    sigma = torch.relu(raw[..., 3])
+    depth_map = raw2outputs(raw, z_vals, rays_d)[4]
+    return rgb, sigma, depth_map
+
+
+def render_test_ray(rays_o, rays_d, hwf, ndc, near, far, use_viewdirs, N_samples, network, network_query_fn, **kwargs):
+    """run_nerf.py:350-377: evenly spaced depths between near and far for the given rays, one network query."""
+    from .render import ndc_rays
+    H, W, focal = hwf
+    viewdirs = None
+    if use_viewdirs:
+        viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+        viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    if ndc:
+        rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
+    rays_o = torch.reshape(rays_o, [-1, 3]).float()
+    rays_d = torch.reshape(rays_d, [-1, 3]).float()
+    near_t, far_t = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+    t_vals = torch.linspace(0., 1., steps=N_samples, device=rays_d.device)
+    z_vals = (near_t * (1. - t_vals) + far_t * t_vals).reshape([rays_o.shape[0], N_samples])
+    rgb, sigma, depth_maps = sample_sigma(rays_o, rays_d, viewdirs, network, z_vals, network_query_fn)
+    return rgb, sigma, z_vals, depth_maps

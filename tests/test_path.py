@@ -113,3 +113,49 @@ def test_render_sharded_single_rank_is_render():
     got = S.render_sharded(H, W, f, c2w, chunk, kw)
     for a, b in zip(got, ref[:4]):
         assert torch.equal(a, b)
+
+
+def test_convert_pose_flips_y_and_z():
+    import spin_nerf_amd as S
+    c = np.arange(16, dtype=np.float64).reshape(4, 4)
+    out = S.convert_pose(c)
+    assert np.array_equal(out[:, 0], c[:, 0]) and np.array_equal(out[:, 1], -c[:, 1])
+    assert np.array_equal(out[:, 2], -c[:, 2]) and np.array_equal(out[:, 3], c[:, 3])
+
+
+@pytest.mark.gpu
+def test_projection_and_test_ray_helpers():
+    """render_path_projection (run_nerf.py:310-339) returns render()'s own z_vals / weights; render_test_ray
+    (:350-377) agrees with the CPU oracle's network + compositing on evenly spaced depths."""
+    import spin_nerf_amd as S
+    from oracle import nerf_oracle as O
+    from test_gpu_render import build
+    from helpers import render_case_nets
+    g = load("render_c2w_fine_vd")
+    _, _, kw = build(S, g)
+    H, W, f, chunk = int(g["H"]), int(g["W"]), float(g["focal"]), int(g["chunk"])
+    c2w = T(g["c2w"]).cuda()
+    poses = torch.stack([c2w, c2w], 0)
+    z, w, c2ws, K = S.render_path_projection(poses, (H, W, f), chunk, kw)
+    with torch.no_grad():
+        ex = S.render(H, W, f, chunk=chunk, c2w=c2w[:3, :4], retraw=True, **kw)[4]
+    assert np.array_equal(z[1], ex["z_vals"].cpu().numpy()) and np.array_equal(w[0], ex["weights"].cpu().numpy())
+    full = np.concatenate([c2w[:3, :4].cpu().numpy(), [[0, 0, 0, 1]]], 0)
+    assert np.allclose(c2ws[0], S.convert_pose(full)) and K[0, 2] == W / 2
+
+    ro, rd = S.get_rays(H, W, f, c2w[:3, :4])
+    ro, rd = ro[::3, ::4].reshape(-1, 3), rd[::3, ::4].reshape(-1, 3)
+    near, far = float(g["near"]), float(g["far"])
+    with torch.no_grad():
+        rgb, sigma, zv, depth = S.render_test_ray(ro, rd, (H, W, f), False, near, far, True, 48, kw["network_fn"],
+                                                  kw["network_query_fn"])
+    sd_c, _ = render_case_nets(g)
+    ro_c, rd_c = ro.cpu(), rd.cpu()
+    vd = rd_c / rd_c.norm(dim=-1, keepdim=True)
+    zr = near * (1 - torch.linspace(0, 1, 48)) + far * torch.linspace(0, 1, 48)
+    zr = zr.expand(ro_c.shape[0], 48)
+    raw = O.run_network(sd_c, ro_c[:, None] + rd_c[:, None] * zr[..., None], vd)
+    np.testing.assert_allclose(zv.cpu().numpy(), zr.numpy(), atol=1e-6)
+    np.testing.assert_allclose(rgb.cpu().numpy(), torch.sigmoid(raw[..., :3]).numpy(), atol=2e-5)
+    np.testing.assert_allclose(sigma.cpu().numpy(), torch.relu(raw[..., 3]).numpy(), atol=2e-4, rtol=2e-5)
+    np.testing.assert_allclose(depth.cpu().numpy(), O.raw2outputs(raw, zr, rd_c)[4].numpy(), rtol=2e-4, atol=1e-5)
