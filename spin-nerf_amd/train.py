@@ -69,7 +69,7 @@ class RenderTrainer:
         return loss, rgb.detach()
 
     def spin_loss(self, H, W, focal, batch_rays_clf, target_clf, batch_rays, target_s, batch_inp=None,
-                  depth_inp=None, chunk=1024 * 32, randoms=None, **extra):
+                  depth_inp=None, chunk=1024 * 32, randoms=None, batched=False, **extra):
         """Loss of one SPIn-NeRF iteration in its default mode (run_nerf.py:1455-1521, no --masked_NeRF /
         --object_removal / --prepare / --no_geometry, LPIPS and COLMAP-depth terms excluded — SURVEY.md §8 f-1):
 
@@ -79,10 +79,25 @@ class RenderTrainer:
                                                                  skipped when NaN like the reference (:1518-1521)
 
         ``randoms`` = optional list of three injected-random dicts (one per render, as for render()) so that
-        parity tests can pin the draws.  Returns (loss, dict of the three render outputs)."""
+        parity tests can pin the draws.  ``batched`` runs the first and the third render as one.
+        Returns (loss, dict of the three render outputs)."""
         rnd = randoms or [None, None, None]
         kw = dict(chunk=chunk, retraw=True, **extra, **self.kw)
-        rgb, disp, acc, depth, ex = render(H, W, focal, rays=batch_rays_clf, randoms=rnd[0], **kw)
+        ex_i = disp_i = None
+        if batched and batch_inp is not None:
+            # the two renders that do not detach the weights share one launch sequence (rays are independent,
+            # chunking does not change results): 2 x N_rand rays through render(), outputs split afterwards
+            n = batch_rays_clf.shape[1]
+            both = torch.cat([batch_rays_clf, batch_inp], 1)
+            r2 = None
+            if rnd[0] is not None and rnd[2] is not None:
+                r2 = {k: torch.cat([rnd[0][k], rnd[2][k]], 0) for k in rnd[0]}
+            rgb2, disp2, acc2, depth2, ex2 = render(H, W, focal, rays=both, randoms=r2, **kw)
+            rgb, disp, acc, depth = rgb2[:n], disp2[:n], acc2[:n], depth2[:n]
+            ex = {k: v[:n] for k, v in ex2.items()}
+            disp_i, ex_i = disp2[n:], {k: v[n:] for k, v in ex2.items()}
+        else:
+            rgb, disp, acc, depth, ex = render(H, W, focal, rays=batch_rays_clf, randoms=rnd[0], **kw)
         rgb_c, _, _, _, ex_c = render(H, W, focal, rays=batch_rays, detach_weights=True, randoms=rnd[1], **kw)
         loss = img2mse(rgb, target_clf) + img2mse(rgb_c, target_s)
         if 'rgb0' in ex_c:
@@ -91,7 +106,8 @@ class RenderTrainer:
             loss = loss + img2mse(ex['rgb0'], target_clf)
         outs = {"clf": (rgb, disp, acc, depth, ex), "complete": (rgb_c, ex_c)}
         if batch_inp is not None:
-            _, disp_i, _, _, ex_i = render(H, W, focal, rays=batch_inp, randoms=rnd[2], **kw)
+            if disp_i is None:
+                _, disp_i, _, _, ex_i = render(H, W, focal, rays=batch_inp, randoms=rnd[2], **kw)
             inp = img2mse(disp_i, depth_inp)
             if 'disp0' in ex_i:
                 inp = inp + img2mse(ex_i['disp0'], depth_inp)

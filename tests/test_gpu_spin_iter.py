@@ -75,6 +75,17 @@ def test_spin_iteration_loss_and_gradients_match_oracle():
             rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
             assert rel < 5e-3, f"{k}: relative L2 error {rel:.2e}"
 
+    # the batched form (first and third render in one launch sequence) gives the same loss and gradients
+    g_ref = [n.flat.grad.clone() for n in (net_c, net_f)]
+    for n in (net_c, net_f):
+        n.flat.grad = None
+    loss_b, _ = tr.spin_loss(H, W, focal, cu(rays_clf), cu(t_clf), cu(rays_all), cu(t_all), cu(rays_inp), cu(d_inp),
+                             randoms=[{k: cu(v) for k, v in r.items()} for r in rnds], batched=True)
+    assert abs(float(loss_b.detach()) - float(loss.detach())) < 1e-6 * abs(float(loss.detach()))
+    loss_b.backward()
+    for n, gr in zip((net_c, net_f), g_ref):
+        assert float((n.flat.grad - gr).norm() / gr.norm()) < 1e-5
+
     # the optimiser step runs and reports a PSNR
     l2, psnr = tr.spin_iteration(H, W, focal, cu(rays_clf), cu(t_clf), cu(rays_all), cu(t_all), cu(rays_inp), cu(d_inp))
     assert np.isfinite(float(l2)) and np.isfinite(float(psnr)) and tr.global_step == 1
