@@ -63,7 +63,12 @@ template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4;
 //    instead let every weight fragment feed two MFMAs;
 //  * fp32 (parity path): 4 waves x 1 tile — its activations alone are 256 registers.
 template <int P, bool TRAIN> struct ChainCfg { static constexpr int WAVES = 4, NJ = 1; };
+// (4 waves x 2 tiles with the asm reads: 113 spilled dwords, 0.281 vs 0.226 ms at 196 608 samples)
+#if defined(SNR_INFER_WAVES) && defined(SNR_INFER_NJ)   // A/B builds only
+template <> struct ChainCfg<kBF16, false> { static constexpr int WAVES = SNR_INFER_WAVES, NJ = SNR_INFER_NJ; };
+#else
 template <> struct ChainCfg<kBF16, false> { static constexpr int WAVES = 8, NJ = 1; };
+#endif
 // training forward / dgrad, bf16: A/B on MI355X (196 608 samples, non-temporal activation stores):
 // 4 waves x 2 tiles = 0.373 / 0.286 ms vs 4 x 1 = 0.384 / 0.331 ms; 8 waves x 1 spills and is slower.
 #if defined(SNR_TRAIN_WAVES) && defined(SNR_TRAIN_NJ)   // A/B builds only
