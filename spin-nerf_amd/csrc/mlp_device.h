@@ -191,8 +191,9 @@ template <int P, int WAVES_> struct Pipe {
   //  * init(nt) supplies the initial accumulator: either an f32x16 value, or the LDS byte address of
   //    this lane's 16 bias floats (4 x 16 B, 32 B apart) — those are read one output tile ahead;
   //    finish(nt, j, acc) is the epilogue; the epilogues of output tile nt-1 are placed behind the
-  //    first MFMAs of tile nt so that their VALU work sits in the shadow of that tile's MFMA chain
-  //    (one wave per SIMD: nothing else would hide it);
+  //    first MFMAs of tile nt so that their VALU work sits in the shadow of that tile's MFMA chain when there
+  //    is one wave per SIMD (WAVES == 4); with two per SIMD the partner wave covers it and the epilogue runs
+  //    straight after its tile (keeping the previous accumulator measured no gain and costs 16 registers);
   //  * pre(nt) issues tile nt's slice of the deferred global stores (the previous stage's output):
   //    spread over the tiles so that no burst of stores sits in front of the counted DMA waits.
   template <int KA, int KB, int NT, int NJ, int SA, int SB, class Init, class Finish, class Pre>

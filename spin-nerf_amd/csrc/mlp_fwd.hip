@@ -4,11 +4,11 @@
 // DS_NeRF/run_nerf_helpers.py:22-70, 104-127).  See mlp_layout.h for the data layout and
 // DESIGN.md for the roofline.
 //
-// Workgroup = 4 waves (one per SIMD, up to 512 VGPR+AGPR each); each wave owns a tile of 32
-// samples and carries its activations in registers through all 11 linear layers (the C tile of
-// layer i is, after bias/ReLU/convert, directly the B operand of layer i+1).  The weights of one
-// 32-neuron output tile ("chunk", KS KiB) are DMA'd global->LDS (global_load_lds_dwordx4) into a
-// two-slot ring shared by the 4 waves, one chunk ahead of the MFMAs that consume them.
+// Workgroup = ChainCfg waves (bf16: 8, two per SIMD; fp32: 4); each wave owns a tile of 32 samples and
+// carries its activations in registers through all 11 linear layers (the C tile of layer i is, after
+// bias/ReLU/convert, directly the B operand of layer i+1).  The packed weights stream global->LDS
+// (global_load_lds_dwordx4) through a ring of 16 KiB blocks shared by the waves, several blocks ahead of the
+// MFMAs that consume them (mlp_device.h: Pipe); fragment and bias reads are inline asm with counted waits.
 #include <type_traits>
 
 #include "snr_common.h"

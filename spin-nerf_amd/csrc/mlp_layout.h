@@ -52,25 +52,21 @@ template <> struct Prec<kBF16> { static constexpr int EPF = 8, FPT = 2, ESZ = 2;
 template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4; };
 
 // Shape of a chained-kernel workgroup (forward, dgrad): WAVES waves, each owning NJ tiles of 32 samples.
-// Measured on MI355X (196 608 samples, bf16 forward): every LDS-DMA instruction blocks its issuing
-// wave ~170 cycles and a wave re-reads all 16 weight fragments of each block, so with one wave per SIMD
-// the matrix pipe idles during both.
-//  * inference forward, bf16: 8 waves = two per SIMD (a wave stuck in DMA issue or an epilogue is
-//    covered by its SIMD partner); needs <= 256 registers per wave, which fits once the encodings are
-//    re-derived where consumed instead of kept (1044 TFLOP/s vs 965 at 4 waves x 2 tiles, 817 at 4 x 1);
-//  * training forward and dgrad, bf16: 4 waves x 2 tiles — with saved-activation stores and masks they
-//    spill at 256 registers (measured 47 / 76 dwords, slower), so they stay at one wave per SIMD and
-//    instead let every weight fragment feed two MFMAs;
+//  * bf16 (inference forward, training forward, dgrad): 8 waves x 1 tile = two waves per SIMD in <= 256
+//    architectural VGPRs each, no AGPRs (the epilogue reads MFMA results without v_accvgpr copies); the
+//    encodings are re-derived where consumed instead of kept.  History of the A/B measurements on MI355X at
+//    196 608 samples: before the LDS reads became inline asm the compiler drained the DMA queue at every block
+//    (which looked like "each LDS-DMA instruction blocks its wave ~170 cycles") and 4 waves x 2 tiles was the
+//    best training shape (0.373 / 0.286 ms forward / dgrad vs 0.384 / 0.331 at 4 x 1); with the asm reads
+//    4 x 2 runs out of registers (139 spilled dwords) and 8 x 1 with packed epilogues is 0.33 / 0.28 ms;
+//    inference 8 x 1: 0.21 ms = 1100 TFLOP/s (4 x 2: 113 spilled dwords, 0.281 ms).
 //  * fp32 (parity path): 4 waves x 1 tile — its activations alone are 256 registers.
 template <int P, bool TRAIN> struct ChainCfg { static constexpr int WAVES = 4, NJ = 1; };
-// (4 waves x 2 tiles with the asm reads: 113 spilled dwords, 0.281 vs 0.226 ms at 196 608 samples)
 #if defined(SNR_INFER_WAVES) && defined(SNR_INFER_NJ)   // A/B builds only
 template <> struct ChainCfg<kBF16, false> { static constexpr int WAVES = SNR_INFER_WAVES, NJ = SNR_INFER_NJ; };
 #else
 template <> struct ChainCfg<kBF16, false> { static constexpr int WAVES = 8, NJ = 1; };
 #endif
-// training forward / dgrad, bf16: A/B on MI355X (196 608 samples, non-temporal activation stores):
-// 4 waves x 2 tiles = 0.373 / 0.286 ms vs 4 x 1 = 0.384 / 0.331 ms; 8 waves x 1 spills and is slower.
 #if defined(SNR_TRAIN_WAVES) && defined(SNR_TRAIN_NJ)   // A/B builds only
 template <> struct ChainCfg<kBF16, true> { static constexpr int WAVES = SNR_TRAIN_WAVES, NJ = SNR_TRAIN_NJ; };
 #else
