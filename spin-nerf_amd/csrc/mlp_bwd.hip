@@ -5,16 +5,17 @@
 // encodings / sample positions (nothing upstream needs one).
 //
 // Three kernels:
-//   1. dgrad chain  — same structure as the forward (4 waves x 32-sample tiles, activations in
-//      registers, W^T chunks DMA'd through LDS): d z_{i-1}^T = relu'(h_{i-1}) * (W_i^T d z_i^T).
-//      ReLU masks come from the 1-bit-per-activation masks the forward saved; every d z_i is
-//      written (bf16 / fp32 fragments) for the weight-gradient pass.
+//   1. dgrad chain  — same structure as the forward (ChainCfg waves x 32-sample tiles, activations in
+//      registers, W^T blocks DMA'd through LDS): d z_{i-1}^T = relu'(h_{i-1}) * (W_i^T d z_i^T).
+//      ReLU flags come from the 1 bit per activation the forward saved (asm loads with counted
+//      completion); every d z_i is written (bf16 / fp32 fragments, asm streaming stores) for the
+//      weight-gradient pass.
 //   2. wgrad        — dW_i[n][k] = sum_s d z_i[s][n] h_{i-1}[s][k]: a contraction over SAMPLES, so
 //      both operands need 8 consecutive samples per lane while the saved fragments hold 8
 //      consecutive neurons per lane.  Tiles are DMA'd to LDS unchanged and transposed on the way
-//      out with ds_read_b64_tr_b16 (bf16) / per-lane ds_read_b32 (fp32).  Each workgroup owns the
-//      whole (<= 256 x 256) output of one layer for a slice of the samples (split-K); the kernel is
-//      HBM-bound (1 KB of saved activations per 131 KFLOP).
+//      out with ds_read_b64_tr_b16 (bf16, inline asm) / per-lane ds_read_b32 (fp32).  Each workgroup owns
+//      the whole (<= 256 x 256) output of one layer for a slice of the samples (split-K, exactly one
+//      workgroup per CU); the kernel is HBM-bound (11.4 KB streamed per 1.19 MFLOP).
 //   3. reduce       — sums the split-K partials and scatters them from fragment order to the
 //      reference's [out, in] parameter layout (+ bias gradients).
 #include <type_traits>
