@@ -148,3 +148,117 @@ def build_ray_table(poses, images, labels, H, W, focal, i_train):
     t = np.transpose(t, [0, 2, 3, 1, 4])
     t = np.stack([t[i] for i in i_train], 0)
     return np.reshape(t, [-1, 3, 4]).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# file-reading half (load_llff.py:68-190).  Parity with the reference is NOT pinned here: it reads through imageio
+# and dilates / resizes with cv2, neither of which exists in the build container; PNG decoding is lossless (PIL
+# gives the same bytes), the 5x5 dilation and the nearest-neighbour resize are checked against scipy / by hand.
+# ----------------------------------------------------------------------------------------------------------------
+_IMG_EXT = ('JPG', 'jpg', 'jpeg', 'png')
+
+
+def _imread(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im)
+
+
+def dilate(msk, ksize=5, iterations=5):
+    """cv2.dilate(msk, ones((k,k)), iterations=n): n passes of a k x k maximum filter; pixels outside the image do
+    not take part (cv2's default border for dilation)."""
+    r = ksize // 2
+    out = np.asarray(msk, dtype=np.float64)
+    H, W = out.shape
+    for _ in range(iterations):
+        pad = np.full((H + 2 * r, W + 2 * r), -np.inf)
+        pad[r:r + H, r:r + W] = out
+        out = np.max(np.stack([pad[i:i + H, j:j + W] for i in range(ksize) for j in range(ksize)], 0), 0)
+    return out
+
+
+def resize_nearest(a, H, W):
+    """cv2.resize(..., interpolation=INTER_NEAREST): source index = floor(dst * src / dst_size)."""
+    ys = np.minimum((np.arange(H) * (a.shape[0] / H)).astype(np.int64), a.shape[0] - 1)
+    xs = np.minimum((np.arange(W) * (a.shape[1] / W)).astype(np.int64), a.shape[1] - 1)
+    return a[ys][:, xs]
+
+
+def load_llff_folder(basedir, factor=None, prepare=False, lpips=False, load_imgs=True):
+    """_load_data (load_llff.py:68-190) for a folder whose down-scaled image directories already exist
+    (`images_<factor>`; the reference shells out to ImageMagick to create them): poses_bounds.npy -> poses [3,5,N]
+    with the hwf column set from the image size and the factor, bds [2,N]; images from `images<sfx>/lama_images`
+    (or `images<sfx>` with prepare=True) / 255; masks from `images<sfx>/label/<stem>.png`, scaled to [0,1],
+    dilated 5x5 five times (-1 everywhere when the file is missing), sign-flipped for all but the fifth-last view
+    when `lpips` (load_llff.py:162-163), divided by their global maximum; depths from `images<sfx>/depth` / 255."""
+    import os
+    arr = np.load(os.path.join(basedir, 'poses_bounds.npy'))
+    poses = arr[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0])
+    bds = arr[:, -2:].transpose([1, 0])
+    sfx = '' if factor is None else '_{}'.format(factor)
+    factor = 1 if factor is None else factor
+    imgdir = os.path.join(basedir, 'images' + sfx) if prepare else os.path.join(basedir, 'images' + sfx, 'lama_images')
+    mskdir = os.path.join(basedir, 'images' + sfx, 'label')
+    depthdir = os.path.join(basedir, 'images' + sfx, 'depth')
+    if not os.path.exists(imgdir):
+        raise FileNotFoundError(f"{imgdir} does not exist (down-scaled image folders are not generated here)")
+    names = [f for f in sorted(os.listdir(imgdir)) if f.endswith(_IMG_EXT)]
+    imgfiles = [os.path.join(imgdir, f) for f in names]
+    mskfiles = [os.path.join(mskdir, f.split('.')[0] + '.png') for f in names if 'cutout' not in f and 'pseudo' not in f]
+    try:
+        depthfiles = [os.path.join(depthdir, f.split('.')[0] + '.png') for f in sorted(os.listdir(depthdir))
+                      if f.endswith(_IMG_EXT)]
+    except OSError:
+        depthfiles = mskfiles
+    if poses.shape[-1] > len(imgfiles):
+        poses = poses[:, :, :len(imgfiles)]
+    if poses.shape[-1] != len(imgfiles):
+        raise ValueError('Mismatch between imgs {} and poses {}'.format(len(imgfiles), poses.shape[-1]))
+    sh = _imread(imgfiles[0]).shape
+    poses[:2, 4, :] = np.array(sh[:2]).reshape([2, 1])
+    poses[2, 4, :] = poses[2, 4, :] * 1. / factor
+    if not load_imgs:
+        return poses, bds
+    imgs = np.stack([_imread(f)[..., :3] / 255. for f in imgfiles], -1)
+    H, W = imgs.shape[0], imgs.shape[1]
+
+    def plane(f, scale_by_max):
+        m = _imread(f)
+        m = m / (m.max() if scale_by_max else 255.)
+        if m.ndim > 2:
+            m = m[:, :, 0]
+        if m.shape != (H, W):
+            m = resize_nearest(m, H, W)
+        return m
+
+    masks, mask_indices = [], []
+    for i, f in enumerate(mskfiles):
+        try:
+            m = dilate(plane(f, True), 5, 5)
+            mask_indices.append(i)
+            if (i != len(mskfiles) - 5) and (not prepare) and lpips:
+                m = m * (-1)
+            masks.append(m)
+        except (OSError, ValueError):
+            masks.append(-np.ones((H, W)))
+    depths = []
+    for f in depthfiles:
+        try:
+            depths.append(plane(f, False))
+        except (OSError, ValueError):
+            depths.append(-np.ones((H, W)))
+    masks = np.stack(masks, -1)
+    masks = masks / np.max(masks)
+    return poses, bds, imgs, masks, np.stack(depths, -1), mask_indices
+
+
+def load_llff_data(basedir, factor=8, recenter=True, bd_factor=.75, spherify=False, path_zflat=False,
+                   spherify_hack=True, prepare=False, lpips=False):
+    """load_llff_data (load_llff.py:315-433): (images [N,H,W,3], poses [N,3,5], bds [N,2], render_poses, i_test,
+    masks [N,H,W], inpainted_depths [N,H,W], mask_indices), all float32."""
+    poses, bds, imgs, masks, depths, mask_indices = load_llff_folder(basedir, factor=factor, prepare=prepare, lpips=lpips)
+    images = np.moveaxis(imgs, -1, 0).astype(np.float32)
+    masks = np.moveaxis(masks, -1, 0).astype(np.float32)
+    depths = np.moveaxis(depths, -1, 0).astype(np.float32)
+    poses, bds, render_poses, i_test = llff_poses(poses, bds, recenter, bd_factor, spherify, path_zflat, spherify_hack)
+    return images, poses, bds, render_poses, i_test, masks, depths, mask_indices

@@ -56,3 +56,52 @@ def test_ray_table_layout():
         assert np.array_equal(blk[..., 2, :3], images[i])
         for r in range(3):
             assert np.array_equal(blk[..., r, 3], labels[i])
+
+
+def test_dilate_and_resize_against_independent_implementations():
+    from scipy import ndimage
+    rs = np.random.RandomState(2)
+    m = (rs.rand(23, 31) > 0.9).astype(np.float64) * rs.rand(23, 31)
+    ref = m
+    for _ in range(5):
+        ref = ndimage.grey_dilation(ref, size=(5, 5), mode="constant", cval=-np.inf)
+    assert np.array_equal(P.dilate(m, 5, 5), ref)
+    a = np.arange(12.0).reshape(3, 4)
+    assert np.array_equal(P.resize_nearest(a, 6, 8), np.repeat(np.repeat(a, 2, 0), 2, 1))
+    assert np.array_equal(P.resize_nearest(a, 3, 2), a[:, [0, 2]])
+
+
+def test_load_llff_folder_round_trip(tmp_path):
+    """A synthetic LLFF folder written with the package's own PNG encoder: images, masks (one missing), depths."""
+    S = importlib.import_module("spin-nerf_amd")
+    g = load("poses_default")
+    N, H, W = 7, 6, 8
+    rs = np.random.RandomState(4)
+    base = tmp_path / "scene"
+    for d in ("images_2/lama_images", "images_2/label", "images_2/depth"):
+        (base / d).mkdir(parents=True)
+    arr = np.concatenate([np.moveaxis(g["poses_in"], -1, 0).reshape(N, 15), np.moveaxis(g["bds_in"], -1, 0)], 1)
+    np.save(base / "poses_bounds.npy", arr)
+    imgs = rs.randint(0, 256, size=(N, H, W, 3)).astype(np.uint8)
+    msk = (rs.rand(N, H, W) > 0.8).astype(np.uint8) * 255
+    dep = rs.randint(0, 256, size=(N, H, W)).astype(np.uint8)
+    for i in range(N):
+        S.write_png(str(base / "images_2/lama_images" / f"{i:03d}.png"), imgs[i])
+        if i != 3:
+            S.write_png(str(base / "images_2/label" / f"{i:03d}.png"), msk[i])
+        S.write_png(str(base / "images_2/depth" / f"{i:03d}.png"), dep[i])
+    images, poses, bds, render_poses, i_test, masks, depths, idx = P.load_llff_data(str(base), factor=2)
+    assert images.shape == (N, H, W, 3) and images.dtype == np.float32
+    np.testing.assert_allclose(images, imgs / 255.0, atol=1e-7)
+    np.testing.assert_allclose(depths, dep / 255.0, atol=1e-7)
+    assert idx == [0, 1, 2, 4, 5, 6] and np.all(masks[3] == -1)
+    for i in idx:
+        np.testing.assert_allclose(masks[i], P.dilate(msk[i] / 255.0, 5, 5), atol=1e-7)
+    # hwf column: image size, focal / factor; the rest equals the pose-only path with that column set
+    pin = g["poses_in"].copy()
+    pin[:2, 4, :] = np.array([H, W]).reshape(2, 1)
+    pin[2, 4, :] = pin[2, 4, :] / 2
+    p2, b2, r2, t2 = P.llff_poses(pin, g["bds_in"].copy())
+    assert np.array_equal(poses, p2) and np.array_equal(bds, b2) and np.array_equal(render_poses, r2) and i_test == t2
+    with pytest.raises(FileNotFoundError):
+        P.load_llff_data(str(base), factor=8)
