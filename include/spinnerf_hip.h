@@ -115,6 +115,11 @@ int snr_sample_fine(const float* z_coarse, const float* weights, const float* u,
                     int n_coarse, int n_fine, float* z_out, float* z_samples, float* z_std,
                     snr_stream_t stream);
 
+/* sample_pdf alone (helpers:304-347) for callers that hold their own bins: bins [n_rays, n_bins], weights
+ * [n_rays, n_bins-1], u [n_rays, n_samples] or NULL (= linspace(0,1,n_samples)); samples [n_rays, n_samples]. */
+int snr_sample_pdf(const float* bins, const float* weights, const float* u, int64_t n_rays, int n_bins,
+                   int n_samples, float* samples, snr_stream_t stream);
+
 /* ---- rays: replaces get_rays + ndc_rays + the ray packing of render() (helpers:249-300,
  * run_nerf.py:117-153).  Writes rows [o(3) d(3) near far (viewdirs(3))] for the pixel rectangle
  * [i0,i0+h) x [j0,j0+w) of an H x W pinhole camera with pose c2w_host (12 floats, HOST memory). */

@@ -9,10 +9,11 @@ The directory name carries a hyphen (it mirrors the reference repo's name), so i
 from . import _lib
 from ._lib import HipLibraryError, LIB_PATH
 from .nerf import NeRF, NeRF_RGB
-from .ops import raw2outputs, raw2outputs_mvseg, sample_coarse, sample_fine, make_rays, mlp_query, adam_step_
+from .ops import raw2outputs, raw2outputs_mvseg, sample_pdf, sample_coarse, sample_fine, make_rays, mlp_query, adam_step_
 from .render import (render, render_rays, batchify_rays, batchify, run_network, create_nerf, get_embedder, get_rays,
                      ndc_rays, Embedder)
 from .loss import SigmaLoss
+from .poses import get_rays_np, get_rays_by_coord_np
 from .path import (render_path, render_sharded, render_path_projection, render_test_ray, sample_sigma, convert_pose,
                    to8b, write_png)
 
@@ -20,5 +21,5 @@ img2mse = lambda x, y: ((x - y) ** 2).mean()                      # helpers:15
 mse2psnr = lambda x: -10. * x.log() / 2.302585092994046           # helpers:17
 
 __all__ = ["NeRF", "NeRF_RGB", "render", "render_rays", "batchify_rays", "batchify", "run_network", "create_nerf",
-           "get_embedder", "get_rays", "ndc_rays", "raw2outputs", "raw2outputs_mvseg", "sample_coarse", "sample_fine", "make_rays",
-           "mlp_query", "adam_step_", "img2mse", "mse2psnr", "HipLibraryError", "LIB_PATH", "Embedder", "SigmaLoss", "render_path", "render_sharded", "render_path_projection", "render_test_ray", "sample_sigma", "convert_pose", "to8b", "write_png"]
+           "get_embedder", "get_rays", "ndc_rays", "raw2outputs", "raw2outputs_mvseg", "sample_pdf", "sample_coarse", "sample_fine", "make_rays",
+           "mlp_query", "adam_step_", "img2mse", "mse2psnr", "HipLibraryError", "LIB_PATH", "Embedder", "SigmaLoss", "get_rays_np", "get_rays_by_coord_np", "render_path", "render_sharded", "render_path_projection", "render_test_ray", "sample_sigma", "convert_pose", "to8b", "write_png"]

@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
                                                           const float* __restrict__ weights,
                                                           const float* __restrict__ u_in, int64_t n_rays, int Nc, int Nf,
                                                           int npow2, float* __restrict__ z_out,
-                                                          float* __restrict__ z_samples, float* __restrict__ z_std) {
+                                                          float* __restrict__ z_samples, float* __restrict__ z_std,
+                                                          int direct) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
@@ -250,8 +251,10 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
   float* bins = cdf + nb;
   float* srt = bins + nb;
   if (ray >= n_rays) return;  // whole wave exits together; barriers below are wave-local
-  const float* zc = z_coarse + ray * Nc;
-  const float* wr = weights + ray * Nc;
+  // direct (snr_sample_pdf): z_coarse holds the nb bin positions themselves and weights the nb-1 bin weights;
+  // no union / sort.  Otherwise bins are the midpoints of z_coarse and the pdf comes from weights[1:-1].
+  const float* zc = z_coarse + ray * (direct ? nb : Nc);
+  const float* wr = direct ? weights + ray * (nb - 1) - 1 : weights + ray * Nc;
 
   // pdf = (w[1:-1] + 1e-5) / sum   (helpers:306-307; the slice is run_nerf.py:699)
   float tot = 0.f;
@@ -267,8 +270,9 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     carry = __shfl(inc, kWave - 1, kWave);
   }
   if (lane == 0) cdf[0] = 0.f;
-  for (int i = lane; i < nb; i += kWave) bins[i] = .5f * (zc[i + 1] + zc[i]);  // run_nerf.py:697
-  for (int i = lane; i < Nc; i += kWave) srt[i] = zc[i];
+  for (int i = lane; i < nb; i += kWave) bins[i] = direct ? zc[i] : .5f * (zc[i + 1] + zc[i]);  // run_nerf.py:697
+  if (!direct)
+    for (int i = lane; i < Nc; i += kWave) srt[i] = zc[i];
   for (int i = Nc + Nf + lane; i < npow2; i += kWave) srt[i] = __builtin_inff();
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
   var = wave_sum(var);
   if (lane == 0 && z_std) z_std[ray] = sqrtf(var / (float)Nf);
 
+  if (direct) return;
   // bitonic sort of srt[0..npow2) ascending (values only, run_nerf.py:702)
   for (int k = 2; k <= npow2; k <<= 1) {
     for (int jj = k >> 1; jj > 0; jj >>= 1) {
@@ -516,7 +521,30 @@ extern "C" int snr_sample_fine(const float* z_coarse, const float* weights, cons
   {
     ProfScope ps(K_SAMPLE_FINE, (hipStream_t)stream);
     sample_fine_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(z_coarse, weights, u, n_rays, Nc, Nf, npow2,
-                                                                            z_out, z_samples, z_std);
+                                                                            z_out, z_samples, z_std, 0);
+  }
+  return launch_status();
+}
+
+extern "C" int snr_sample_pdf(const float* bins, const float* weights, const float* u, int64_t n_rays, int n_bins,
+                              int n_samples, float* samples, snr_stream_t stream) {
+  SNR_CHECK_ARG(bins && weights && samples, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_rays > 0 && n_bins >= 2 && n_samples > 0, SNR_ERR_SHAPE);
+  const int Nc = n_bins + 1;
+  int npow2 = 2;
+  while (npow2 < Nc + n_samples) npow2 <<= 1;
+  const size_t lds = (size_t)kRaysPerBlock * (2 * (Nc - 1) + npow2) * sizeof(float);
+  SNR_CHECK_ARG(lds <= 160 * 1024, SNR_ERR_SHAPE);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)sample_fine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  {
+    ProfScope ps(K_SAMPLE_FINE, (hipStream_t)stream);
+    sample_fine_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(bins, weights, u, n_rays, Nc, n_samples, npow2,
+                                                                            nullptr, samples, nullptr, 1);
   }
   return launch_status();
 }

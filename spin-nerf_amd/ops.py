@@ -45,6 +45,30 @@ def sample_fine(z_coarse, weights, N_importance, u=None):
 # ----------------------------------------------------------------------------------------------
 # alpha compositing (helpers:350-401)
 # ----------------------------------------------------------------------------------------------
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
+    """The reference's sample_pdf (helpers:304-347) with its signature: bins [N, nb], weights [N, nb-1] ->
+    samples [N, N_samples] (no gradient, like the reference's `.detach()`ed use).  ``pytest`` reproduces its numpy
+    seed-0 draws; ``u`` injects them."""
+    import numpy as np
+    lib = _lib.load()
+    b, w = f32c(bins.detach()), f32c(weights.detach())
+    n = b.shape[0]
+    if u is None:
+        if pytest:
+            np.random.seed(0)
+            if det:
+                u = torch.Tensor(np.broadcast_to(np.linspace(0., 1., N_samples), (n, N_samples)).copy())
+            else:
+                u = torch.Tensor(np.random.rand(n, N_samples))
+            u = u.to(b.device)
+        elif not det:
+            u = torch.rand(n, N_samples, device=b.device)
+    uc = f32c(u) if u is not None else None
+    out = torch.empty(n, N_samples, device=b.device, dtype=torch.float32)
+    check(lib.snr_sample_pdf(ptr(b), ptr(w), ptr(uc), n, b.shape[1], N_samples, ptr(out), stream()), "snr_sample_pdf")
+    return out
+
+
 class _Composite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw, z_vals, rays, noise, white_bkgd, detach_weights, need_alpha):

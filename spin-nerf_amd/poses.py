@@ -139,6 +139,14 @@ def get_rays_np(H, W, focal, c2w):
     return rays_o, rays_d
 
 
+def get_rays_by_coord_np(H, W, focal, c2w, coords):
+    """run_nerf_helpers.py:275-280: rays through the given (x, y) pixel coordinates [n, 2] (COLMAP key points)."""
+    x, y = (coords[:, 0] - W * .5) / focal, -(coords[:, 1] - H * .5) / focal
+    dirs = np.stack([x, y, -np.ones_like(x)], -1)
+    rays_d = np.sum(dirs[..., np.newaxis, :] * c2w[:3, :3], -1)
+    return np.broadcast_to(c2w[:3, -1], np.shape(rays_d)), rays_d
+
+
 def build_ray_table(poses, images, labels, H, W, focal, i_train):
     """run_nerf.py:1228-1247: rows [ro | rd | rgb] x (xyz, label) for every pixel of the training views,
     shape [n_train*H*W, 3, 4] float32 (label = mask value or inpainted depth of the pixel, repeated)."""

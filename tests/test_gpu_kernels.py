@@ -422,3 +422,14 @@ def test_mlp_other_encoder_sizes_forward_and_backward(S, L, Lv, vd):
         out16 = mk("bf16").query(pts.cuda(), dirs.cuda() if vd else None)
     err = (out16.cpu() - ref.detach()).abs()
     assert float(err.max()) < 0.05 * float(ref.abs().max()) + 1e-2, float(err.max())
+
+
+@pytest.mark.parametrize("name", PDF_CASES)
+def test_sample_pdf_with_the_reference_signature(S, name):
+    """snr_sample_pdf on the fixtures' own bins / weights / u: the reference's output itself."""
+    g = load(name)
+    bins, w, u = T(g["bins"]).cuda(), T(g["w"]).cuda(), T(g["u"]).cuda()
+    out = S.sample_pdf(bins, w, u.shape[1], det=bool(g["det"]), u=u)
+    close(out, g["out"], atol=2e-5, rtol=1e-5)
+    if bool(g["det"]):
+        close(S.sample_pdf(bins, w, u.shape[1], det=True), g["out"], atol=2e-5, rtol=1e-5)

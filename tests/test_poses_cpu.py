@@ -105,3 +105,15 @@ def test_load_llff_folder_round_trip(tmp_path):
     assert np.array_equal(poses, p2) and np.array_equal(bds, b2) and np.array_equal(render_poses, r2) and i_test == t2
     with pytest.raises(FileNotFoundError):
         P.load_llff_data(str(base), factor=8)
+
+
+def test_rays_by_coordinate_pick_the_same_rays_as_the_full_grid():
+    g = load("poses_default")
+    c2w = g["poses"][2, :3, :4]
+    H, W, focal = 6, 8, 9.0
+    ro, rd = P.get_rays_np(H, W, focal, c2w)
+    coords = np.array([[0, 0], [3, 2], [7, 5]], dtype=np.float32)      # (x, y)
+    ro_c, rd_c = P.get_rays_by_coord_np(H, W, focal, c2w, coords)
+    for n, (x, y) in enumerate(coords.astype(int)):
+        np.testing.assert_allclose(rd_c[n], rd[y, x], atol=1e-6)
+        np.testing.assert_allclose(ro_c[n], ro[y, x], atol=0)
