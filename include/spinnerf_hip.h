@@ -127,9 +127,20 @@ int snr_make_rays(int H, int W, float focal, const float* c2w_host, int i0, int 
                   float near, float far, int use_viewdirs, float* rays, int ray_ld, snr_stream_t stream);
 
 /* Same rows from rays the caller already holds (render(rays=...), run_nerf.py:117-153 incl. the viewdir
- * normalisation :128-135 and ndc_rays :140): rays_o, rays_d [n_rays,3] contiguous device memory. */
-int snr_pack_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int H, int W, float focal, int ndc,
-                  float near, float far, int use_viewdirs, float* rays, int ray_ld, snr_stream_t stream);
+ * normalisation :128-135 and ndc_rays :140): rays_o, rays_d [n_rays,3] contiguous device memory.  Optional (NULL =
+ * absent): view_src [n_rays,3] = directions the viewdirs are taken from instead of rays_d (c2w_staticcam, :131-133);
+ * near_rows / far_rows [n_rays] = per-ray bounds instead of the scalars (:106-107); depths [n_rays] = the COLMAP depth
+ * column inserted in front of the viewdirs (:148-149).  ndc_near = the near plane of ndc_rays (render() passes 1).
+ * Row = o(3) d(3) near far [depth] [viewdirs(3)]. */
+int snr_pack_rays(const float* rays_o, const float* rays_d, const float* view_src, int64_t n_rays, int H, int W,
+                  float focal, int ndc, float ndc_near, float near, float far, const float* near_rows,
+                  const float* far_rows, const float* depths, int use_viewdirs, float* rays, int ray_ld,
+                  snr_stream_t stream);
+
+/* ---- positional encoding as a standalone op: replaces Embedder.embed (helpers:22-52) for callers of
+ * get_embedder()[0]; x [n, n_cols] -> out [n, n_cols * (1 + 2 * multires)] = [x, sin(2^k x), cos(2^k x), k < multires].
+ * (The MLP entry points fuse the encoding and never materialise it.) */
+int snr_embed(const float* x, int64_t n, int n_cols, int multires, float* out, snr_stream_t stream);
 
 /* ---- loss of one training step: replaces img2mse(rgb, target) [+ img2mse(rgb0, target)] and its autograd
  * (helpers:15, run_nerf.py:1482-1490).  a, b (may be NULL), target: n elements each.  loss[0] = the sum of the

@@ -48,7 +48,8 @@ SIGNATURES = {
     "snr_sample_fine": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p, _p]),
     "snr_make_rays": (_i, [_i, _i, _f, _c.POINTER(_f), _i, _i, _i, _i, _i, _f, _f, _i, _p, _i, _p]),
     "snr_sample_pdf": (_i, [_p, _p, _p, _l, _i, _i, _p, _p]),
-    "snr_pack_rays": (_i, [_p, _p, _l, _i, _i, _f, _i, _f, _f, _i, _p, _i, _p]),
+    "snr_pack_rays": (_i, [_p, _p, _p, _l, _i, _i, _f, _i, _f, _f, _f, _p, _p, _p, _i, _p, _i, _p]),
+    "snr_embed": (_i, [_p, _l, _i, _i, _p, _p]),
     "snr_mse_pair": (_i, [_p, _p, _p, _l, _p, _p, _p, _p]),
     "snr_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),
     "snr_prof_enable": (_i, [_i]),

@@ -229,12 +229,7 @@ template <int P, bool VD>
 static int launch_dgrad(const DgradArgs& a, hipStream_t s) {
   const int64_t n_wg = padded_tiles<P>(a.n_samples) / (ChainCfg<P, true>::WAVES * ChainCfg<P, true>::NJ);
   const int lds = kRingBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_dgrad_kernel<P, VD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (int e = ensure_dynamic_lds<&mlp_dgrad_kernel<P, VD>>(lds)) return e;
   const int64_t grid = n_wg < 1024 ? n_wg : 1024;
   {
     ProfScope ps(K_MLP_DGRAD, s);
@@ -268,12 +263,7 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   w.ws = (const char*)ws;
   w.part = (float*)((char*)ws + WsLayout<P>(n, c->use_viewdirs).dz_bytes());
   constexpr int lds = WgradCfg<P>::RING * 2 * Blob<P>::KS_H * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_wgrad_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (int e = ensure_dynamic_lds<&mlp_wgrad_kernel<P>>(lds)) return e;
   {
     ProfScope ps(K_MLP_WGRAD, s);
     mlp_wgrad_kernel<P><<<dim3((unsigned)total_splits), dim3(64 * kWgradWaves), lds, s>>>(w);

@@ -408,13 +408,7 @@ static int launch_fwd(const FwdArgs& a, hipStream_t s) {
   constexpr int per_wg = ChainCfg<P, TRAIN>::WAVES * ChainCfg<P, TRAIN>::NJ;
   const int64_t n_wg = (padded_tiles<P>(a.n_samples) + per_wg - 1) / per_wg;
   const int lds = kBiasLdsBytes + kRingBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<P, VD, TRAIN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (int e = ensure_dynamic_lds<&mlp_fwd_kernel<P, VD, TRAIN>>(lds)) return e;
   const int64_t grid = n_wg < 1024 ? n_wg : 1024;  // one workgroup per CU is resident; the rest grid-stride
   {
     ProfScope ps(K_MLP_FWD, s);

@@ -331,15 +331,19 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 struct Pose { float m[12]; };
 
-// one packed row [o d near far (viewdirs)]: viewdirs normalised BEFORE the NDC warp (run_nerf.py:128-135)
-__device__ __forceinline__ void write_ray_row(float* o, float* d, int H, int W, float focal, int ndc, float near,
-                                              float far, int use_viewdirs, float* __restrict__ out) {
+// one packed row [o d near far (depth) (viewdirs)]: viewdirs = vsrc / |vsrc| taken BEFORE the NDC warp
+// (run_nerf.py:128-135; vsrc = d unless c2w_staticcam swaps the camera), depth column per run_nerf.py:148-149
+__device__ __forceinline__ void write_ray_row(float* o, float* d, const float* vsrc, int H, int W, float focal, int ndc,
+                                              float ndc_near, float near, float far, const float* depth,
+                                              int use_viewdirs, float* __restrict__ out) {
+  int col = 8;
+  if (depth) out[col++] = *depth;
   if (use_viewdirs) {
-    const float n = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    out[8] = d[0] / n; out[9] = d[1] / n; out[10] = d[2] / n;
+    const float n = sqrtf(vsrc[0] * vsrc[0] + vsrc[1] * vsrc[1] + vsrc[2] * vsrc[2]);
+    out[col] = vsrc[0] / n; out[col + 1] = vsrc[1] / n; out[col + 2] = vsrc[2] / n;
   }
-  if (ndc) {  // ndc_rays with near = 1 (run_nerf.py:140)
-    const float nr = 1.f;
+  if (ndc) {  // ndc_rays (helpers:283-300); render() calls it with near = 1 (run_nerf.py:140)
+    const float nr = ndc_near;
     const float t = -(nr + o[2]) / d[2];
     const float ox = o[0] + t * d[0], oy = o[1] + t * d[1], oz = o[2] + t * d[2];
     const float sx = -1.f / ((float)W / (2.f * focal)), sy = -1.f / ((float)H / (2.f * focal));
@@ -366,18 +370,41 @@ __global__ void make_rays_kernel(int H, int W, float focal, Pose c2w, int i0, in
     d[r] = dx * c2w.m[4 * r] + dy * c2w.m[4 * r + 1] + dz * c2w.m[4 * r + 2];
     o[r] = c2w.m[4 * r + 3];
   }
-  write_ray_row(o, d, H, W, focal, ndc, near, far, use_viewdirs, rays + idx * ld);
+  const float v[3] = {d[0], d[1], d[2]};
+  write_ray_row(o, d, v, H, W, focal, ndc, 1.f, near, far, nullptr, use_viewdirs, rays + idx * ld);
 }
 
-// rows from rays the caller already holds (render(rays=...), run_nerf.py:117-153): same row as above
-__global__ void pack_rays_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, int64_t n,
-                                 int H, int W, float focal, int ndc, float near, float far, int use_viewdirs,
+// rows from rays the caller already holds (render(rays=...), run_nerf.py:117-153): same row as above, plus the
+// optional pieces of render(): viewing directions from a second camera (c2w_staticcam, :131-133), per-ray near / far
+// (:106-107), the COLMAP depth column (:148-149)
+__global__ void pack_rays_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                 const float* __restrict__ view_src, int64_t n, int H, int W, float focal, int ndc,
+                                 float ndc_near, float near, float far, const float* __restrict__ near_rows,
+                                 const float* __restrict__ far_rows, const float* __restrict__ depths, int use_viewdirs,
                                  float* __restrict__ rays, int ld) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   float o[3] = {rays_o[3 * idx], rays_o[3 * idx + 1], rays_o[3 * idx + 2]};
   float d[3] = {rays_d[3 * idx], rays_d[3 * idx + 1], rays_d[3 * idx + 2]};
-  write_ray_row(o, d, H, W, focal, ndc, near, far, use_viewdirs, rays + idx * ld);
+  const float* vs = view_src ? view_src + 3 * idx : rays_d + 3 * idx;
+  const float v[3] = {vs[0], vs[1], vs[2]};
+  write_ray_row(o, d, v, H, W, focal, ndc, ndc_near, near_rows ? near_rows[idx] : near, far_rows ? far_rows[idx] : far,
+                depths ? depths + idx : nullptr, use_viewdirs, rays + idx * ld);
+}
+
+// positional encoding as a standalone op (Embedder.embed, helpers:22-52): out[i] = [x, sin(2^0 x), cos(2^0 x), ...,
+// sin(2^(L-1) x), cos(2^(L-1) x)], C input columns, C * (1 + 2L) output columns.  The MLP kernels fuse the encoding;
+// this serves callers of get_embedder()[0] (run_nerf.py:383-388).
+__global__ void embed_kernel(const float* __restrict__ x, int64_t n, int C, int L, float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int od = C * (1 + 2 * L);
+  if (idx >= n * od) return;
+  const int64_t row = idx / od;
+  const int c = (int)(idx - row * od);
+  if (c < C) { out[idx] = x[row * C + c]; return; }
+  const int k = (c - C) / (2 * C), r = (c - C) % (2 * C);
+  const float v = x[row * C + (r % C)] * __builtin_ldexpf(1.0f, k);   // freq_bands = 2^k exactly (helpers:36-39)
+  out[idx] = r < C ? sinf(v) : cosf(v);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -565,16 +592,26 @@ extern "C" int snr_make_rays(int H, int W, float focal, const float* c2w_host, i
   return launch_status();
 }
 
-extern "C" int snr_pack_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int H, int W, float focal,
-                             int ndc, float near, float far, int use_viewdirs, float* rays, int ld,
+extern "C" int snr_pack_rays(const float* rays_o, const float* rays_d, const float* view_src, int64_t n_rays, int H,
+                             int W, float focal, int ndc, float ndc_near, float near, float far, const float* near_rows,
+                             const float* far_rows, const float* depths, int use_viewdirs, float* rays, int ld,
                              snr_stream_t stream) {
   SNR_CHECK_ARG(rays_o && rays_d && rays, SNR_ERR_NULL);
-  SNR_CHECK_ARG(n_rays > 0 && H > 0 && W > 0 && ld >= (use_viewdirs ? 11 : 8), SNR_ERR_SHAPE);
+  SNR_CHECK_ARG(n_rays > 0 && H > 0 && W > 0 && ld >= 8 + (depths ? 1 : 0) + (use_viewdirs ? 3 : 0), SNR_ERR_SHAPE);
   {
     ProfScope ps(K_MAKE_RAYS, (hipStream_t)stream);
     pack_rays_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        rays_o, rays_d, n_rays, H, W, focal, ndc, near, far, use_viewdirs, rays, ld);
+        rays_o, rays_d, view_src, n_rays, H, W, focal, ndc, ndc_near, near, far, near_rows, far_rows, depths,
+        use_viewdirs, rays, ld);
   }
+  return launch_status();
+}
+
+extern "C" int snr_embed(const float* x, int64_t n, int n_cols, int multires, float* out, snr_stream_t stream) {
+  SNR_CHECK_ARG(x && out, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n > 0 && n_cols > 0 && multires >= 0 && multires <= 24, SNR_ERR_SHAPE);
+  const int64_t total = n * n_cols * (1 + 2 * multires);
+  embed_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, n, n_cols, multires, out);
   return launch_status();
 }
 

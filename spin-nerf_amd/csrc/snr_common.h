@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/spinnerf_hip.h"
 #include "mlp_layout.h"
 #include "prof.h"
@@ -26,6 +28,21 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SNR_OK : (int)e;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it once per (kernel, device),
+// from whichever thread launches first (forward and autograd threads both do).  Returns 0 or the hipError_t.
+template <auto Kernel> inline int ensure_dynamic_lds(int bytes) {
+  static std::atomic<uint64_t> done{0};   // one bit per device ordinal
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  e = hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
 }
 
 // ---- MFMA policies --------------------------------------------------------------------------

@@ -42,6 +42,8 @@ def _layer_specs(D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs)
 
 
 class NeRF(nn.Module):
+    _UNREGISTERED = ()   # layer names present in the flat buffer but not in the reference module (NeRF_RGB)
+
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False,
                  precision=None):
         super().__init__()
@@ -64,7 +66,10 @@ class NeRF(nn.Module):
         # nn.Linear default init, drawn in the reference's construction order so that the same
         # torch seed yields the same network as the reference (helpers:86-102)
         chunks = []
-        for _, fout, fin in self._specs:
+        for name, fout, fin in self._specs:
+            if name in self._UNREGISTERED:   # a block the kernels need but the reference module never constructs:
+                chunks += [torch.zeros(fout * fin), torch.zeros(fout)]   # zeros, and no draw from the RNG stream
+                continue
             lin = nn.Linear(fin, fout)
             chunks += [lin.weight.detach().reshape(-1), lin.bias.detach().reshape(-1)]
         self.flat = nn.Parameter(torch.cat(chunks))
@@ -77,6 +82,7 @@ class NeRF(nn.Module):
             raise RuntimeError(f"flat layout mismatch: {self.flat.numel()} vs C ABI {n_expected}")
         self._packed = None
         self._packed_key = None
+        self.pack_generation = 0   # bumped on every (in-place) re-pack; autograd contexts check it (ops._Mlp)
 
     # ---- flat <-> named views --------------------------------------------------------------
     def named_views(self, flat=None):
@@ -86,6 +92,12 @@ class NeRF(nn.Module):
             out[name + ".weight"] = flat[o:o + fout * fin].view(fout, fin); o += fout * fin
             out[name + ".bias"] = flat[o:o + fout]; o += fout
         return out
+
+    def param_views(self, flat=None):
+        """views of the parameters the REFERENCE module registers, in its registration order (the layout of
+        `grad_vars` and of the per-layer Adam state in checkpoints, run_nerf.py:398-434)"""
+        return OrderedDict((k, v) for k, v in self.named_views(flat).items()
+                           if k.rsplit(".", 1)[0] not in self._UNREGISTERED)
 
     def _linear(self, name):
         v = self.named_views(self.flat.detach())
@@ -144,6 +156,7 @@ class NeRF(nn.Module):
                 self._packed = torch.empty(nbytes, device=self.flat.device, dtype=torch.uint8)
             check(lib.snr_mlp_pack(self.cfg, ptr(self.flat.detach()), ptr(self._packed), stream()), "snr_mlp_pack")
             self._packed_key = key
+            self.pack_generation += 1
         return self._packed
 
     def mark_weights_changed(self):
@@ -194,19 +207,16 @@ class NeRF_RGB(NeRF):
     (its output is replaced, hence its gradient is zero and Adam never moves it); the state dict follows the
     reference: no `alpha_linear.*`, and the `alpha_model.*` entries of the registered sub-module."""
 
+    _UNREGISTERED = ("alpha_linear",)   # helpers:183-185: commented out in the reference's NeRF_RGB
+
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False,
                  alpha_model=None, precision=None):
         super().__init__(D=D, W=W, input_ch=input_ch, input_ch_views=input_ch_views, output_ch=output_ch, skips=skips,
                          use_viewdirs=use_viewdirs, precision=precision)
-        if self.use_viewdirs:
-            with torch.no_grad():
-                v = self.named_views(self.flat)
-                v["alpha_linear.weight"].zero_()
-                v["alpha_linear.bias"].zero_()
         self.alpha_model = alpha_model
 
     def _own_views(self, flat):
-        return OrderedDict((k, v) for k, v in self.named_views(flat).items() if not k.startswith("alpha_linear."))
+        return self.param_views(flat)
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         for k, v in self._own_views(self.flat if keep_vars else self.flat.detach()).items():

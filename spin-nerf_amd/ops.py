@@ -164,15 +164,38 @@ def make_rays(H, W, focal, c2w, patch=None, ndc=True, near=0., far=1., use_viewd
     return rays
 
 
-def pack_rays(rays_o, rays_d, H, W, focal, ndc=True, near=0., far=1., use_viewdirs=False):
-    """Packed rows for rays the caller already holds: one kernel instead of norm / div / ones / cat."""
+def pack_rays(rays_o, rays_d, H, W, focal, ndc=True, near=0., far=1., use_viewdirs=False, view_src=None, depths=None,
+              ndc_near=1.):
+    """Packed rows [o d near far (depth) (viewdirs)] for rays the caller already holds (run_nerf.py:117-153): one
+    kernel instead of norm / div / ones / cat.  ``near`` / ``far`` may be per-ray tensors (:106-107), ``view_src`` =
+    the directions viewdirs are taken from (c2w_staticcam, :131-133), ``depths`` = the COLMAP depth column (:148-149)."""
     lib = _lib.load()
     o, d = f32c(rays_o.detach().reshape(-1, 3)), f32c(rays_d.detach().reshape(-1, 3))
-    ld = 11 if use_viewdirs else 8
-    rays = torch.empty(o.shape[0], ld, device=o.device, dtype=torch.float32)
-    check(lib.snr_pack_rays(ptr(o), ptr(d), o.shape[0], int(H), int(W), float(focal), int(bool(ndc)), float(near),
-                            float(far), int(bool(use_viewdirs)), ptr(rays), ld, stream()), "snr_pack_rays")
+    n = o.shape[0]
+
+    def rows(t):   # per-ray bound: anything that broadcasts against [n, 1] like the reference's near * ones_like(...)
+        return f32c(t.detach().to(o.device).reshape(-1, 1).expand(n, 1).reshape(-1))
+    near_t = rows(near) if isinstance(near, torch.Tensor) else None
+    far_t = rows(far) if isinstance(far, torch.Tensor) else None
+    vs = f32c(view_src.detach().reshape(-1, 3)) if view_src is not None else None
+    dp = f32c(depths.detach().reshape(-1)) if depths is not None else None
+    ld = 8 + (1 if dp is not None else 0) + (3 if use_viewdirs else 0)
+    rays = torch.empty(n, ld, device=o.device, dtype=torch.float32)
+    check(lib.snr_pack_rays(ptr(o), ptr(d), ptr(vs), n, int(H), int(W), float(focal), int(bool(ndc)), float(ndc_near),
+                            0. if near_t is not None else float(near), 0. if far_t is not None else float(far),
+                            ptr(near_t), ptr(far_t), ptr(dp), int(bool(use_viewdirs)), ptr(rays), ld, stream()),
+          "snr_pack_rays")
     return rays
+
+
+def embed(x, multires):
+    """Embedder.embed (helpers:22-52) as a standalone op: [..., C] -> [..., C * (1 + 2 * multires)]."""
+    lib = _lib.load()
+    xc = f32c(x.detach().reshape(-1, x.shape[-1]))
+    out = torch.empty(xc.shape[0], xc.shape[1] * (1 + 2 * multires), device=xc.device, dtype=torch.float32)
+    if xc.shape[0]:
+        check(lib.snr_embed(ptr(xc), xc.shape[0], xc.shape[1], int(multires), ptr(out), stream()), "snr_embed")
+    return out.reshape(list(x.shape[:-1]) + [out.shape[-1]])
 
 
 def mse_pair(a, b, target):
@@ -205,6 +228,8 @@ class _Mlp(torch.autograd.Function):
         act = None
         if need_grad:
             nbytes = lib.snr_mlp_act_bytes(cfg, n_samples)
+            if nbytes <= 0:
+                check(int(nbytes), "snr_mlp_act_bytes")
             act = torch.empty(nbytes, device=flat.device, dtype=torch.uint8)
         vd_ld = viewdirs.stride(0) if viewdirs is not None else 0
         check(lib.snr_mlp_forward(cfg, ptr(packed), ptr(pts), ptr(rays), rays.shape[1] if rays is not None else 0,
@@ -212,6 +237,9 @@ class _Mlp(torch.autograd.Function):
               "snr_mlp_forward")
         ctx.net, ctx.n_samples = net, n_samples
         ctx.act, ctx.packed = act, packed
+        # the packed blob is re-packed IN PLACE when the parameters or the precision change: remember which pack this
+        # graph was recorded against
+        ctx.pack_gen, ctx.cfg_key = net.pack_generation, cfg.key()
         ctx.set_materialize_grads(False)
         return raw
 
@@ -223,8 +251,17 @@ class _Mlp(torch.autograd.Function):
         lib = _lib.load()
         net, n = ctx.net, ctx.n_samples
         cfg = net.cfg
+        if ctx.act is None:
+            raise RuntimeError("the saved activations of this MLP evaluation were released by its first backward "
+                               "(retain_graph / a second backward through the same forward is not supported)")
+        if net.pack_generation != ctx.pack_gen or cfg.key() != ctx.cfg_key:
+            raise RuntimeError("the network's packed weights changed between forward and backward (optimizer step, "
+                               "load_state_dict or set_precision in between): re-run the forward")
         g = torch.empty_like(net.flat)
-        ws = torch.empty(lib.snr_mlp_bwd_ws_bytes(cfg, n), device=g.device, dtype=torch.uint8)
+        ws_bytes = lib.snr_mlp_bwd_ws_bytes(cfg, n)
+        if ws_bytes <= 0:
+            check(int(ws_bytes), "snr_mlp_bwd_ws_bytes")
+        ws = torch.empty(ws_bytes, device=g.device, dtype=torch.uint8)
         check(lib.snr_mlp_backward(cfg, ptr(ctx.packed), ptr(f32c(d_raw)), n, ptr(ctx.act), ptr(ws), ptr(g), 0,
                                    stream()), "snr_mlp_backward")
         ctx.act = None

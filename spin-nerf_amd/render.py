@@ -25,8 +25,9 @@ DEBUG = False
 # embedders (helpers:22-70) — the encoding itself is fused into the MLP kernel
 # ----------------------------------------------------------------------------------------------
 class Embedder:
-    """Descriptor of a positional encoding: ``out_dim`` = 3 + 6*multires (helpers:43-49).
-    The sin/cos evaluation happens inside the fused kernel, so this object is only a shape carrier."""
+    """Positional encoding (helpers:22-52): ``out_dim`` = 3 + 6*multires (helpers:43-49); calling it returns
+    [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)] like ``embed_fn`` of the reference
+    (snr_embed kernel).  The render path never calls it: the MLP kernels fuse the encoding."""
 
     def __init__(self, multires, identity=False):
         self.multires = 0 if identity else multires
@@ -34,8 +35,11 @@ class Embedder:
         self.out_dim = 3 if identity else 3 + 6 * multires
 
     def __call__(self, x):
-        raise NotImplementedError("positional encoding is fused into the HIP MLP kernel; call network_query_fn / "
-                                  "NeRF.query instead of embedding on the host")
+        if self.identity:                  # nn.Identity() (helpers:56-57)
+            return x
+        return ops.embed(x, self.multires)
+
+    embed = __call__                       # the reference's method name (helpers:51-52)
 
 
 def get_embedder(multires, i=0):
@@ -230,7 +234,9 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True,
            patch=None,
            **kwargs):
     """Render rays (run_nerf.py:90-165) -> [rgb_map, disp_map, acc_map, depth_map, extras]."""
-    if c2w is not None and c2w_staticcam is None and depths is None and not isinstance(near, torch.Tensor):
+    simple = (c2w_staticcam is None or not use_viewdirs) and depths is None and not isinstance(near, torch.Tensor) \
+        and not isinstance(far, torch.Tensor)
+    if c2w is not None and simple:
         # full frame / patch: rays, viewdirs (before NDC), the NDC warp and the packing in one kernel
         dev = c2w.device if isinstance(c2w, torch.Tensor) and c2w.is_cuda else torch.device("cuda")
         if patch is not None:
@@ -241,14 +247,10 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True,
         rays_flat = ops.make_rays(H, W, focal, c2w, patch=pr, ndc=ndc, near=float(near), far=float(far),
                                   use_viewdirs=use_viewdirs, device=dev)
         sh = (pr[2], pr[3], 3) if pr is not None else (H, W, 3)
-    elif (c2w is None and c2w_staticcam is None and depths is None and not isinstance(near, torch.Tensor)
-          and not isinstance(far, torch.Tensor) and rays[1].is_cuda):
-        # rays the caller holds: viewdir normalisation, NDC warp and the packing in one kernel
-        rays_o, rays_d = rays
-        sh = rays_d.shape
-        rays_flat = ops.pack_rays(rays_o, rays_d, H, W, focal, ndc=ndc, near=float(near), far=float(far),
-                                  use_viewdirs=use_viewdirs)
     else:
+        # everything else of run_nerf.py:117-153 — rays the caller holds, a second camera for the viewing directions
+        # (c2w_staticcam), per-ray near / far, the COLMAP depth column — is one packing kernel on top of (at most
+        # two) ray-generation kernels
         if c2w is not None:
             rays_o, rays_d = get_rays(H, W, focal, c2w)
             if patch is not None:
@@ -257,24 +259,17 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True,
                 rays_d = rays_d[i:i + len1, j:j + len2, :]
         else:
             rays_o, rays_d = rays
-        if use_viewdirs:
-            viewdirs = rays_d
-            if c2w_staticcam is not None:
-                rays_o, rays_d = get_rays(H, W, focal, c2w_staticcam)
-            viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
-            viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+            if not rays_d.is_cuda:
+                dev = next((t.device for t in (near, far, depths) if isinstance(t, torch.Tensor) and t.is_cuda),
+                           torch.device("cuda"))
+                rays_o, rays_d = rays_o.to(dev), rays_d.to(dev)
+        view_src = None
+        if use_viewdirs and c2w_staticcam is not None:       # :131-133: whole-frame rays of the static camera
+            view_src = rays_d
+            rays_o, rays_d = get_rays(H, W, focal, c2w_staticcam)
         sh = rays_d.shape
-        if ndc:
-            rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
-        rays_o = torch.reshape(rays_o, [-1, 3]).float()
-        rays_d = torch.reshape(rays_d, [-1, 3]).float()
-        near_t, far_t = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
-        cols = [rays_o, rays_d, near_t, far_t]
-        if depths is not None:
-            cols.append(depths.reshape(-1, 1))
-        if use_viewdirs:
-            cols.append(viewdirs)
-        rays_flat = torch.cat(cols, -1)
+        rays_flat = ops.pack_rays(rays_o, rays_d, H, W, focal, ndc=ndc, near=near, far=far, use_viewdirs=use_viewdirs,
+                                  view_src=view_src, depths=depths)
 
     all_ret = batchify_rays(rays_flat, chunk, need_alpha=need_alpha, detach_weights=detach_weights, **kwargs)
     for k in all_ret:
@@ -288,22 +283,49 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True,
 
 
 def ndc_rays(H, W, focal, near, rays_o, rays_d):
-    """NDC warp of caller-provided ray tensors (helpers:283-300).  Element-wise ray preparation on
-    tensors the caller already holds in HBM; full frames go through the ray kernel instead."""
-    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
-    rays_o = rays_o + t[..., None] * rays_d
-    o0 = -1. / (W / (2. * focal)) * rays_o[..., 0] / rays_o[..., 2]
-    o1 = -1. / (H / (2. * focal)) * rays_o[..., 1] / rays_o[..., 2]
-    o2 = 1. + 2. * near / rays_o[..., 2]
-    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
-    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
-    d2 = -2. * near / rays_o[..., 2]
-    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+    """NDC warp of caller-provided ray tensors (helpers:283-300) -> (rays_o, rays_d) of the input shape; the warp is
+    the packing kernel's (snr_pack_rays), read back from its rows."""
+    dev = rays_d.device if rays_d.is_cuda else torch.device("cuda")
+    rows = ops.pack_rays(rays_o.to(dev), rays_d.to(dev), H, W, focal, ndc=True, near=0., far=0., ndc_near=float(near))
+    return rows[:, 0:3].reshape(rays_o.shape), rows[:, 3:6].reshape(rays_d.shape)
 
 
 # ----------------------------------------------------------------------------------------------
 # create_nerf (run_nerf.py:380-496)
 # ----------------------------------------------------------------------------------------------
+def _load_per_layer_adam(optimizer, osd, nets):
+    """Load a reference-format optimizer state (one entry per layer tensor, coarse network first) into the Adam over
+    the networks' flat parameters.  Raises when the layouts do not correspond — a resumed run must not silently
+    restart its moments, bias correction and learning-rate decay."""
+    st = osd.get('state', {})
+    n_params = sum(len(n.param_views()) for n in nets)
+    groups = osd.get('param_groups') or [{}]
+    if len(groups[0].get('params', [])) == len(optimizer.param_groups[0]['params']) != n_params:
+        optimizer.load_state_dict(osd)     # written by this build's own flat-parameter optimizer
+        return
+    if osd.get('param_groups'):
+        for g in optimizer.param_groups:
+            g['lr'] = osd['param_groups'][0]['lr']
+    if not st:
+        return
+    if len(st) != n_params:
+        raise RuntimeError(f"optimizer_state_dict holds Adam state for {len(st)} parameter tensors, these networks "
+                           f"register {n_params} (e.g. --alpha_model_path checkpoints list the frozen density network "
+                           "as well): cannot resume the optimizer")
+    idx = 0
+    for n in nets:
+        m, v = torch.zeros_like(n.flat.data), torch.zeros_like(n.flat.data)
+        steps = set()
+        for mv, vv in zip(n.param_views(m).values(), n.param_views(v).values()):
+            e = st[idx]
+            mv.copy_(e['exp_avg'].reshape(mv.shape)); vv.copy_(e['exp_avg_sq'].reshape(vv.shape))
+            steps.add(float(e['step']))
+            idx += 1
+        if len(steps) != 1:
+            raise RuntimeError(f"layers of one network disagree on the Adam step count: {sorted(steps)}")
+        optimizer.state[n.flat] = {'step': torch.tensor(steps.pop()), 'exp_avg': m, 'exp_avg_sq': v}
+
+
 def create_nerf(args, device=None):
     """Instantiate the coarse/fine MLPs, the query closure, Adam and the render kwargs — same return
     tuple as the reference: (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer)."""
@@ -361,15 +383,14 @@ def create_nerf(args, device=None):
         print('Reloading from', ckpt_path)
         ckpt = torch.load(ckpt_path, map_location=device)
         start = ckpt['global_step']
-        try:
-            optimizer.load_state_dict(ckpt['optimizer_state_dict'])
-        except (ValueError, KeyError):
-            # a reference checkpoint stores per-layer Adam moments; this build keeps one flat buffer
-            print('optimizer state of a per-layer checkpoint not restored (flat-parameter layout)')
         if model is not None:
             model.load_state_dict(ckpt['network_fn_state_dict'])
         if model_fine is not None:
             model_fine.load_state_dict(ckpt['network_fine_state_dict'])
+        # The checkpoint holds torch.optim.Adam state per LAYER tensor in grad_vars order (run_nerf.py:398-434,
+        # 1626-1636); this build's parameters are one flat buffer per network: scatter the moments into flat ones.
+        # RenderTrainer(render_kwargs_train, optimizer=optimizer, start=start) continues from them.
+        _load_per_layer_adam(optimizer, ckpt['optimizer_state_dict'], [m for m in (model, model_fine) if m is not None])
 
     render_kwargs_train = {
         'network_query_fn': network_query_fn,

@@ -21,14 +21,22 @@ def img2mse(x, y):
 
 
 class RenderTrainer:
-    def __init__(self, render_kwargs_train, lrate=5e-4, lrate_decay=250, world_size=1, process_group=None):
+    def __init__(self, render_kwargs_train, lrate=5e-4, lrate_decay=250, world_size=1, process_group=None,
+                 optimizer=None, start=None):
+        """``optimizer`` / ``start`` = what create_nerf() returned: when it reloaded a checkpoint (run_nerf.py:448-462)
+        the Adam moments, the step count and the learning rate it restored continue here (a resumed run must not
+        restart the bias correction and the lr decay); an optimizer whose state does not cover every network raises."""
         self.kw = dict(render_kwargs_train)
         self.nets = [n for n in (self.kw.get('network_fn'), self.kw.get('network_fine')) if n is not None]
         self.lrate, self.lrate_decay = lrate, lrate_decay
         self.world_size, self.pg = world_size, process_group
-        self.global_step = 0
+        self.global_step = 0          # completed optimisation steps (the reference's global_step after its increment)
+        self.opt_step = 0             # Adam's own step count (bias correction)
+        self._lr = lrate              # rate the NEXT step uses (run_nerf.py:1616-1622 sets it after each step)
         self.m = [torch.zeros_like(n.flat.data) for n in self.nets]
         self.v = [torch.zeros_like(n.flat.data) for n in self.nets]
+        if optimizer is not None:
+            self._adopt(optimizer, start)
         # The all-reduce of a net's gradient starts the moment autograd has finished that net (the fine net's
         # runs under the coarse net's backward); apply_gradients() only waits.
         self._works = {}
@@ -40,16 +48,37 @@ class RenderTrainer:
         import torch.distributed as dist
         self._works[i] = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
+    def _adopt(self, optimizer, start):
+        """continue from a torch.optim.Adam over the networks' flat parameters (create_nerf's return value)"""
+        st = optimizer.state
+        have = [n.flat in st and 'exp_avg' in st[n.flat] for n in self.nets]
+        if any(have) and not all(have):
+            raise RuntimeError("the optimizer holds Adam state for some of the networks only; cannot resume")
+        if all(have) and self.nets:
+            steps = []
+            for i, n in enumerate(self.nets):
+                self.m[i].copy_(st[n.flat]['exp_avg']); self.v[i].copy_(st[n.flat]['exp_avg_sq'])
+                steps.append(int(st[n.flat]['step']))
+            if len(set(steps)) != 1:
+                raise RuntimeError(f"networks disagree on the Adam step count: {steps}")
+            self.opt_step = steps[0]
+            self._lr = float(optimizer.param_groups[0]['lr'])
+        if start is not None:
+            self.global_step = int(start)
+
     def broadcast_parameters(self, src=0):
         """identical replicas at start (rank `src`'s init wins)"""
         if self.world_size > 1:
             import torch.distributed as dist
             for n in self.nets:
                 dist.broadcast(n.flat.data, src=src, group=self.pg)
+                n.mark_weights_changed()   # writes through .data do not bump the version the pack cache keys on
 
     def current_lr(self):
-        # run_nerf.py:1616-1620: lrate * 0.1 ** (global_step / (lrate_decay * 1000))
-        return self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 1000)))
+        """learning rate of the next optimisation step.  The reference steps with the optimizer's current rate and then
+        sets lrate * 0.1 ** (global_step / (lrate_decay * 1000)) from the not-yet-incremented global_step
+        (run_nerf.py:1611-1622, 1703): steps 1 and 2 run at lrate, step k >= 2 at lrate * 0.1 ** ((k - 2) / decay_steps)."""
+        return self._lr
 
     def step(self, H, W, focal, batch_rays, target_s, chunk=1024 * 32, **extra):
         """one optimisation step on this rank's ray shard; returns (loss, rgb) detached"""
@@ -136,8 +165,9 @@ class RenderTrainer:
         fn, fine = self.kw.get('network_fn'), self.kw.get('network_fine')
         state, idx = {}, 0
         for n, m, v in zip(self.nets, self.m, self.v):
-            for (k, mv), vv in zip(n.named_views(m).items(), n.named_views(v).values()):
-                state[idx] = {'step': torch.tensor(float(self.global_step)), 'exp_avg': mv.detach().clone(),
+            # param_views: the parameters the reference module registers (NeRF_RGB has no alpha_linear, helpers:183-185)
+            for (k, mv), vv in zip(n.param_views(m).items(), n.param_views(v).values()):
+                state[idx] = {'step': torch.tensor(float(self.opt_step)), 'exp_avg': mv.detach().clone(),
                               'exp_avg_sq': vv.detach().clone()}
                 idx += 1
         group = {'lr': self.current_lr(), 'betas': (0.9, 0.999), 'eps': 1e-8, 'weight_decay': 0, 'amsgrad': False,
@@ -146,7 +176,7 @@ class RenderTrainer:
         return {'global_step': self.global_step,
                 'network_fn_state_dict': fn.state_dict() if fn is not None else None,
                 'network_fine_state_dict': fine.state_dict() if fine is not None else None,
-                'optimizer_state_dict': {'state': state if self.global_step > 0 else {}, 'param_groups': [group]}}
+                'optimizer_state_dict': {'state': state if self.opt_step > 0 else {}, 'param_groups': [group]}}
 
     def save_checkpoint(self, path):
         torch.save(self.state_dict(), path)
@@ -159,16 +189,24 @@ class RenderTrainer:
         if fine is not None and ckpt.get('network_fine_state_dict') is not None:
             fine.load_state_dict(ckpt['network_fine_state_dict'])
         self.global_step = int(ckpt['global_step'])
-        st = ckpt['optimizer_state_dict']['state']
-        idx = 0
+        osd = ckpt['optimizer_state_dict']
+        st = osd['state']
+        n_params = sum(len(n.param_views(m)) for n, m in zip(self.nets, self.m))
+        if st and len(st) != n_params:
+            raise RuntimeError(f"checkpoint holds Adam state for {len(st)} parameters, these networks have {n_params}")
+        idx, steps = 0, set()
         for n, m, v in zip(self.nets, self.m, self.v):
-            for mv, vv in zip(n.named_views(m).values(), n.named_views(v).values()):
+            m.zero_(); v.zero_()
+            for mv, vv in zip(n.param_views(m).values(), n.param_views(v).values()):
                 if idx in st:
                     mv.copy_(st[idx]['exp_avg'].reshape(mv.shape))
                     vv.copy_(st[idx]['exp_avg_sq'].reshape(vv.shape))
-                else:
-                    mv.zero_(); vv.zero_()
+                    steps.add(int(st[idx]['step']))
                 idx += 1
+        if len(steps) > 1:
+            raise RuntimeError(f"checkpoint parameters disagree on the Adam step count: {sorted(steps)}")
+        self.opt_step = steps.pop() if steps else 0
+        self._lr = float(osd['param_groups'][0]['lr']) if osd.get('param_groups') else self.lrate
         for n in self.nets:
             n.mark_weights_changed()
 
@@ -180,12 +218,19 @@ class RenderTrainer:
             import torch.distributed as dist
             for i, n in enumerate(self.nets):   # anything the hooks did not see (gradients set by hand)
                 if i not in self._works:
+                    if n.flat.grad is None:     # a network that took no part in this step still joins the collective
+                        n.flat.grad = torch.zeros_like(n.flat.data)
                     self._start_all_reduce(i, n.flat)
             for w in self._works.values():
                 w.wait()
             self._works.clear()
-        self.global_step += 1
-        lr = self.current_lr()
+        self.opt_step += 1
+        lr = self._lr
         for n, m, v in zip(self.nets, self.m, self.v):
-            ops.adam_step_(n.flat.data, n.flat.grad, m, v, lr, self.global_step, grad_scale=1.0 / self.world_size)
+            if n.flat.grad is None:             # torch.optim.Adam skips parameters without a gradient
+                continue
+            ops.adam_step_(n.flat.data, n.flat.grad, m, v, lr, self.opt_step, grad_scale=1.0 / self.world_size)
             n.mark_weights_changed()   # written through a raw pointer: re-pack before the next forward
+        # run_nerf.py:1616-1622 (rate for the next step, from the global_step before its increment), :1703
+        self._lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 1000)))
+        self.global_step += 1

@@ -49,12 +49,14 @@ def test_size_queries_and_validation_run_on_host(S):
     assert lib.snr_mlp_param_count(bad) == -3              # SNR_ERR_UNSUPPORTED
     assert lib.snr_mlp_pack(cfg, None, None, None) == -1   # SNR_ERR_NULL
     assert lib.snr_sample_coarse(None, 11, 4, 64, 0, None, None, None) == -1
-    assert lib.snr_pack_rays(None, None, 8, 4, 4, 1.0, 0, 0.0, 1.0, 1, None, 11, None) == -1
+    assert lib.snr_pack_rays(None, None, None, 8, 4, 4, 1.0, 0, 1.0, 0.0, 1.0, None, None, None, 1, None, 11, None) == -1
     assert lib.snr_mse_pair(None, None, None, 8, None, None, None, None) == -1
     import ctypes
     one = ctypes.c_void_p(16)   # any non-null address: argument checks come before any device access
-    assert lib.snr_pack_rays(one, one, 8, 4, 4, 1.0, 0, 0.0, 1.0, 1, one, 8, None) == -2    # row too short for viewdirs
-    assert lib.snr_pack_rays(one, one, 0, 4, 4, 1.0, 0, 0.0, 1.0, 0, one, 8, None) == -2    # empty input
+    assert lib.snr_pack_rays(one, one, None, 8, 4, 4, 1.0, 0, 1.0, 0.0, 1.0, None, None, None, 1, one, 8, None) == -2    # row too short for viewdirs
+    assert lib.snr_pack_rays(one, one, None, 8, 4, 4, 1.0, 0, 1.0, 0.0, 1.0, None, None, one, 1, one, 11, None) == -2  # ... for depth + viewdirs
+    assert lib.snr_pack_rays(one, one, None, 0, 4, 4, 1.0, 0, 1.0, 0.0, 1.0, None, None, None, 0, one, 8, None) == -2    # empty input
+    assert lib.snr_embed(None, 4, 3, 10, one, None) == -1 and lib.snr_embed(one, 0, 3, 10, one, None) == -2
     assert lib.snr_mse_pair(one, None, one, 0, one, one, None, None) == -2
     assert lib.snr_mse_pair(one, one, one, 8, one, one, None, None) == -1                   # b without grad_b
     assert b"NULL" in lib.snr_status_string(-1)

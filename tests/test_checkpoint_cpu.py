@@ -64,3 +64,73 @@ def test_checkpoint_is_loadable_by_a_per_layer_adam(tmp_path, monkeypatch):
         assert torch.equal(a["exp_avg"], b["exp_avg"]) and torch.equal(a["exp_avg_sq"], b["exp_avg_sq"])
     for k in ck["network_fine_state_dict"]:
         assert torch.equal(ck["network_fine_state_dict"][k], ck2["network_fine_state_dict"][k])
+
+
+def test_resume_through_create_nerf_continues_like_an_uninterrupted_run(tmp_path, monkeypatch):
+    """create_nerf reloads a reference-format checkpoint (run_nerf.py:448-462); RenderTrainer(optimizer=, start=) adopts
+    the Adam moments, the step count and the decayed learning rate, so the next steps equal those of a run that was
+    never interrupted.  A checkpoint whose optimizer state does not fit raises instead of restarting silently."""
+    import argparse
+    import pytest
+    import spin_nerf_amd as S
+    train = importlib.import_module("spin-nerf_amd.train")
+    monkeypatch.setattr(train.ops, "adam_step_", _cpu_adam)
+    (tmp_path / "run").mkdir()
+    args = argparse.Namespace(multires=10, multires_views=4, i_embed=0, use_viewdirs=True, N_importance=128,
+                              N_samples=64, alpha_model_path=None, netdepth=8, netwidth=256, netdepth_fine=8,
+                              netwidth_fine=256, netchunk=65536, lrate=1e-3, basedir=str(tmp_path), expname="run",
+                              ft_path=None, no_reload=False, perturb=1.0, white_bkgd=True, raw_noise_std=1.0,
+                              dataset_type="llff", no_ndc=True, lindisp=True, sigma_loss=False, no_coarse=False)
+    cpu = torch.device("cpu")
+    torch.manual_seed(3)
+    kw, _, start, _, opt = S.create_nerf(args, device=cpu)
+    assert start == 0
+    tr = train.RenderTrainer(kw, lrate=1e-3, lrate_decay=1, optimizer=opt, start=start)   # fast decay: visible in 6 steps
+    g = torch.Generator().manual_seed(1)
+    grads = [[torch.randn(n.flat.shape, generator=g) * 1e-2 for n in tr.nets] for _ in range(6)]
+
+    def run(t, steps):
+        for gs in steps:
+            for n, gr in zip(t.nets, gs):
+                n.flat.grad = gr.clone()
+            t.apply_gradients()
+    run(tr, grads[:3])
+    assert tr.global_step == 3 and tr.opt_step == 3
+    # the reference's schedule (run_nerf.py:1611-1622, 1703): steps 1, 2 at lrate, step k at lrate * 0.1 ** ((k - 2) / 1000)
+    assert abs(tr.current_lr() - 1e-3 * 0.1 ** (2 / 1000)) < 1e-12
+    tr.save_checkpoint(str(tmp_path / "run" / "000003.tar"))
+    run(tr, grads[3:])                                       # the uninterrupted run
+
+    kw2, _, start2, _, opt2 = S.create_nerf(args, device=cpu)   # picks the checkpoint up
+    assert start2 == 3
+    tr2 = train.RenderTrainer(kw2, lrate=1e-3, lrate_decay=1, optimizer=opt2, start=start2)
+    assert tr2.opt_step == 3 and tr2.global_step == 3 and abs(tr2.current_lr() - 1e-3 * 0.1 ** (2 / 1000)) < 1e-12
+    run(tr2, grads[3:])
+    for a, b in zip(tr.nets, tr2.nets):
+        assert torch.equal(a.flat.detach(), b.flat.detach())
+    for a, b in zip(tr.m + tr.v, tr2.m + tr2.v):
+        assert torch.equal(a, b)
+
+    # a state that does not cover these networks' parameters is an error, not a silent restart
+    ck = torch.load(tmp_path / "run" / "000003.tar", weights_only=False)
+    ck["optimizer_state_dict"]["state"].pop(5)
+    torch.save(ck, tmp_path / "run" / "000004.tar")
+    with pytest.raises(RuntimeError):
+        S.create_nerf(args, device=cpu)
+
+
+def test_nerf_rgb_draws_and_registers_what_the_reference_does():
+    """helpers:159-191: NeRF_RGB never constructs alpha_linear — same seed, same weights as the reference for everything
+    built after it, and no alpha_linear entries among the parameters Adam state is written for."""
+    import spin_nerf_amd as S
+    torch.manual_seed(11)
+    a = S.NeRF_RGB(input_ch=63, input_ch_views=27, use_viewdirs=True)
+    after_a = torch.rand(1)
+    torch.manual_seed(11)
+    for fin, fout in [(63, 256)] + [(256, 256)] * 4 + [(319, 256)] + [(256, 256)] * 2 + [(283, 128), (256, 256), (128, 3)]:
+        torch.nn.Linear(fin, fout)          # the reference's construction order without alpha_linear
+    assert torch.equal(after_a, torch.rand(1))
+    v = a.named_views(a.flat.detach())
+    assert float(v["alpha_linear.weight"].abs().max()) == 0.0 and float(v["alpha_linear.bias"].abs().max()) == 0.0
+    assert not any(k.startswith("alpha_linear") for k in a.param_views()) and len(a.param_views()) == 22
+    assert len(S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True).param_views()) == 24

@@ -90,9 +90,10 @@ def test_mlp_forward_many_tiles_and_ray_form(S):
     with torch.no_grad():
         out = net.query_rays(rays.cuda(), z.cuda(), rays.cuda()[:, -3:])
         out_pts = net.query(pts.cuda(), rays.cuda()[:, 8:11])
-    # pts formed in-kernel use fma-contracted o + d*z: allow the 1-ulp input difference amplified by 2^9 frequencies
     close(out_pts, ref, atol=5e-5, rtol=5e-5)
-    close(out, ref, atol=5e-3, rtol=1e-3)
+    # pts formed in-kernel use a separate multiply and add (mlp_device.h: mul_add_unfused), i.e. exactly torch's
+    # o + d * z: the same gate as for materialised pts
+    close(out, ref, atol=5e-5, rtol=5e-5)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -112,8 +113,12 @@ def test_composite_forward_backward(S, name):
             + (dev(T(g["g_w"])) * w).sum() + (dev(T(g["g_depth"])) * depth).sum())
     loss.backward()
     ref = g["d_raw"]
-    scale = np.abs(ref).max()
-    close(raw.grad / scale, ref / scale, atol=2e-5, rtol=1e-3)
+    assert bool(torch.isfinite(raw.grad).all()), "non-finite compositing gradient"
+    scale = float(np.abs(ref).max())
+    if scale == 0.0:   # an all-zero reference gradient (no density anywhere and no colour gradient): nothing to normalise by
+        close(raw.grad, ref, atol=1e-7, rtol=0)
+    else:
+        close(raw.grad / scale, ref / scale, atol=2e-5, rtol=1e-3)
 
 
 def test_composite_need_alpha_false_returns_none(S):
