@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--n-rand", type=int, default=1024, help="rays per GPU per step")
     ap.add_argument("--n-coarse", type=int, default=64)
     ap.add_argument("--n-fine", type=int, default=128)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frame", action="store_true")
     ns = ap.parse_args()
@@ -216,16 +216,28 @@ def main():
     dom = max((k for k in kernels if k in flops), key=lambda k: kernels[k]["ms_per_step"])
     peak = PEAK_TFLOPS[ns.precision]
     launches = kernels[dom]["launches_per_step"]
-    # HBM bytes per (average) launch of the dominant kernel from the committed PMC passes (profiles/r01_summary.md:
-    # 2 x FETCH_SIZE + WRITE_SIZE KiB, gfx950 correction per MI355X_MICROARCH.md); valid for the default workload
-    traffic = None
+    # HBM bytes from the PMC passes of THIS round (tools/profile.sh -> profiles/rNN_pmc.json: per-kernel average
+    # FETCH_SIZE / WRITE_SIZE KiB per launch of the default workload; 2 x FETCH_SIZE is the gfx950 correction of
+    # MI355X_MICROARCH.md).  Absent file or another workload -> null, never a stale literal.
+    traffic = hbm_step = None
     default_cfg = (ns.precision == "bf16" and ns.n_rand == 1024 and ns.n_coarse == 64 and ns.n_fine == 128)
-    if default_cfg and dom == "mlp_wgrad":
-        traffic = (2 * 7.288e5 + 5.194e4) * 1024
+    pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")) \
+        if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    pmc_src = None
+    if default_cfg and pmc_files:
+        pmc_src = pmc_files[-1]
+        pk = json.load(open(os.path.join(ROOT, "profiles", pmc_src)))["kernels"]
+
+        def launch_bytes(name):
+            e = pk.get(name + "_kernel")
+            return None if e is None else (2 * e.get("FETCH_SIZE_KiB_per_launch", 0.0) + e.get("WRITE_SIZE_KiB_per_launch", 0.0)) * 1024
+        traffic = launch_bytes(dom)
+        per = [(launch_bytes(k), kernels[k]["launches_per_step"]) for k in kernels if launch_bytes(k) is not None]
+        hbm_step = sum(b * n for b, n in per) if per else None
     roofline = {
         "kernel": dom, "bound": "mfma",
         "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kernels[dom]["tflops"] / peak,
-        "traffic": traffic,
+        "traffic": traffic, "traffic_source": pmc_src,
         "flops_per_launch": flops[dom] * evals_per_step / launches,
         "avg_launch_ms": kernels[dom]["ms_per_step"] / launches,
     }
@@ -233,10 +245,11 @@ def main():
     # activations / d z through HBM: bytes each must move per sample (bf16, viewdirs), and
     # the fraction of the 8 TB/s HBM peak that is while the kernel runs.
     if ns.precision == "bf16":
-        wg_elems = ((256 + 64) + 6 * 512 + (256 + 64) + 512 + 512 + (16 + 256) + (128 + 256) + (128 + 32) + (16 + 128))
-        stream_bytes = {"mlp_wgrad": 2 * wg_elems,                               # every (d z, activation) pair read once
-                        "mlp_fwd": 2 * (64 + 8 * 256 + 32 + 256 + 128) + 9 * 32,  # encodings, h0..h7, feat, h9, flags
-                        "mlp_dgrad": 2 * (16 + 8 * 256 + 256 + 128) + 9 * 32}     # d out, d z0..7, d feat, d z9 (+ flags read)
+        # mlp_wgrad.h's job list: (d z0, pe), 6 x (d z_i, h_{i-1}), (d z5, [pe | h4]), ([d z9 | d out], [h7 | dir]), (d out, h9)
+        wg_elems = ((256 + 64) + 6 * 512 + (256 + 64 + 256) + (128 + 16 + 256 + 32) + (16 + 128))
+        stream_bytes = {"mlp_wgrad": 2 * wg_elems,                               # every saved section of a job read once
+                        "mlp_fwd": 2 * (64 + 8 * 256 + 32 + 128) + 9 * 32,        # encodings, h0..h7, h9, flags
+                        "mlp_dgrad": 2 * (16 + 8 * 256 + 128) + 9 * 32}           # d out, d z0..7, d z9 (+ flags read)
         for k, b in stream_bytes.items():
             if k in kernels:
                 gbps = b * evals_per_step / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
@@ -255,6 +268,7 @@ def main():
                    "global_batch_rays": world * ns.n_rand, "parallelism": f"ray-dp{world}"},
         "ms_per_frame_378x504": ms_frame,
         "step_tflops_algorithmic": step_flops / (elapsed / ns.steps) / 1e12,
+        "hbm_bytes_per_step": hbm_step,
         "roofline": roofline,
         "kernels": kernels,
         "ms_per_step_profiled": prof_elapsed / ns.steps * 1e3,

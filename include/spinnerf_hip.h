@@ -79,9 +79,12 @@ int snr_mlp_forward(const snr_mlp_config* cfg, const void* packed, const float* 
                     int samples_per_ray, float* raw, void* act, snr_stream_t stream);
 
 /* d(loss)/d(params) from d(loss)/d(raw).  No gradient flows to pts/viewdirs.
- * grad_params (flat, fp32): overwritten if accumulate == 0, else += . */
-int snr_mlp_backward(const snr_mlp_config* cfg, const void* packed, const float* d_raw, int64_t n_samples,
-                     const void* act, void* ws, float* grad_params, int accumulate, snr_stream_t stream);
+ * `params` = the flat fp32 parameters `packed` was built from (with use_viewdirs the gradients of feature_linear and of
+ * views_linears.0's feature columns are formed from d z9^T h7 and these weights instead of streaming the feature
+ * tensor; may be NULL without viewdirs).  grad_params (flat, fp32): overwritten if accumulate == 0, else += . */
+int snr_mlp_backward(const snr_mlp_config* cfg, const void* packed, const float* params, const float* d_raw,
+                     int64_t n_samples, const void* act, void* ws, float* grad_params, int accumulate,
+                     snr_stream_t stream);
 
 /* ---- stratified sampling: replaces run_nerf.py:646-668 ----
  * z_vals[n_rays, n_samples] from near/far = rays[:,6], rays[:,7]; lindisp per run_nerf.py:647-650;

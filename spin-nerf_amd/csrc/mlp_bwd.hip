@@ -165,7 +165,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
       roll_masks(W6{});
       mask_load(AL.k_mask(6), mk_next);
       stage(IH{}, I1{}, I8{}, IH{}, I1{}, &hA[0][0], &dout[0], &hB[0][0], true,
-            [&](int nt) { ws_store(WL.k_dfeat(), IH{}, &hA[0][0], IH{}, nt, I8{}); });
+            [&](int) {});   // d feat stays in registers: its weight gradient follows from d z9 (mlp_wgrad.h)
     } else {
       mask_load(AL.k_mask(7), mk_cur);
       mask_load(AL.k_mask(6), mk_next);
@@ -215,7 +215,7 @@ static int check_cfg_b(const snr_mlp_config* c) {
 template <int P> static int64_t ws_bytes(const snr_mlp_config* c, int64_t n) {
   int64_t pf; int ts;
   make_jobs<P>(c, n, &pf, &ts);
-  return WsLayout<P>(n, c->use_viewdirs).dz_bytes() + pf * 4;
+  return WsLayout<P>(n, c->use_viewdirs).dz_bytes() + (pf + kPostFloats) * 4;
 }
 
 extern "C" int64_t snr_mlp_bwd_ws_bytes(const snr_mlp_config* c, int64_t n) {
@@ -239,8 +239,8 @@ static int launch_dgrad(const DgradArgs& a, hipStream_t s) {
 }
 
 template <int P>
-static int backward_impl(const snr_mlp_config* c, const void* packed, const float* d_raw, int64_t n, const void* act,
-                         void* ws, float* grad, int accumulate, hipStream_t s) {
+static int backward_impl(const snr_mlp_config* c, const void* packed, const float* params, const float* d_raw, int64_t n,
+                         const void* act, void* ws, float* grad, int accumulate, hipStream_t s) {
   const PackTable T = make_pack_table<P>(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
   const ParamLayout L = make_param_layout(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
   // The reduce kernel stores every parameter a weight-gradient job produces; the only parameters no job
@@ -262,7 +262,8 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   w.act = (const char*)act;
   w.ws = (const char*)ws;
   w.part = (float*)((char*)ws + WsLayout<P>(n, c->use_viewdirs).dz_bytes());
-  constexpr int lds = WgradCfg<P>::RING * 2 * Blob<P>::KS_H * 1024;
+  w.post = w.part + pf;
+  constexpr int lds = WgradCfg<P>::RING * 2 * Blob<P>::KS_H * 1024;   // the largest ring of any job (mlp_wgrad.h)
   if (int e = ensure_dynamic_lds<&mlp_wgrad_kernel<P>>(lds)) return e;
   {
     ProfScope ps(K_MLP_WGRAD, s);
@@ -270,23 +271,30 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   }
   st = launch_status();
   if (st != SNR_OK) return st;
-  const int per_job = 256 * (256 / 4 + 1);   // rows x (4-column groups + the bias thread)
+  const int per_out = 256 * (256 / 4 + 1);   // rows x (4-column groups + the bias thread)
   {
     ProfScope ps(K_MLP_WGRAD_REDUCE, s);
-    mlp_wgrad_reduce_kernel<P><<<dim3((per_job + 255) / 256, (unsigned)w.n_jobs), dim3(256), 0, s>>>(w, grad, accumulate);
+    mlp_wgrad_reduce_kernel<P><<<dim3((per_out + 255) / 256, (unsigned)w.n_outs), dim3(256), 0, s>>>(w, grad, accumulate);
+    if (c->use_viewdirs) {
+      PostArgs pa{};
+      pa.params = params; pa.post = w.post; pa.grad = grad;
+      pa.w_views = (int)L.w_views; pa.ld_views = kW + L.in_dir; pa.w_feat = (int)L.w_feat; pa.b_feat = (int)L.b_feat;
+      pa.accumulate = accumulate;
+      wgrad_post_kernel<P><<<dim3(97), dim3(256), 0, s>>>(pa);
+    }
   }
   return launch_status();
 }
 
-extern "C" int snr_mlp_backward(const snr_mlp_config* c, const void* packed, const float* d_raw, int64_t n,
-                                const void* act, void* ws, float* grad, int accumulate, snr_stream_t stream) {
+extern "C" int snr_mlp_backward(const snr_mlp_config* c, const void* packed, const float* params, const float* d_raw,
+                                int64_t n, const void* act, void* ws, float* grad, int accumulate, snr_stream_t stream) {
   int st = check_cfg_b(c);
   if (st != SNR_OK) return st;
-  SNR_CHECK_ARG(packed && d_raw && act && ws && grad, SNR_ERR_NULL);
+  SNR_CHECK_ARG(packed && d_raw && act && ws && grad && (params || !c->use_viewdirs), SNR_ERR_NULL);
   SNR_CHECK_ARG(n > 0, SNR_ERR_SHAPE);
   hipStream_t s = (hipStream_t)stream;
-  return c->precision == SNR_PREC_BF16 ? backward_impl<kBF16>(c, packed, d_raw, n, act, ws, grad, accumulate, s)
-                                       : backward_impl<kFP32>(c, packed, d_raw, n, act, ws, grad, accumulate, s);
+  return c->precision == SNR_PREC_BF16 ? backward_impl<kBF16>(c, packed, params, d_raw, n, act, ws, grad, accumulate, s)
+                                       : backward_impl<kFP32>(c, packed, params, d_raw, n, act, ws, grad, accumulate, s);
 }
 
 #ifdef SNR_TIMING

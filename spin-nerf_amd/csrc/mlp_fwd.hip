@@ -306,9 +306,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
       pipe.template run_tiles<KS_H, KS_DIR, 4, NJ, KS_H, KS_DIRA>(
           feat, &dir[0][0], [&](int nt) { return bias_tile_addr(bias_lds, kBiasViews + 32 * nt, g); },
           [&](int nt, int jt, f32x16 acc) { tile_out(std::true_type{}, nt, jt, acc, h9 + jt * KS_H + nt * FPT); },
-          [&](int nt) {
-            if constexpr (TRAIN) act_store(AL.k_feat(), IH{}, feat, IH{}, nt, I4{});
-          });
+          [&](int) {});   // feat is not saved (mlp_pack.h: ActLayout)
       // stage 10: rgb
       keep_masks();
       f32x16 acc_c[NJ];

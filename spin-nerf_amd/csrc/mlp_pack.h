@@ -126,8 +126,10 @@ template <int P> struct ActLayout {
   int use_viewdirs;
   SNR_HD ActLayout(int64_t n_samples, int vd) : n_tiles(padded_tiles<P>(n_samples)), use_viewdirs(vd) {}
   // KiB per tile of each section
+  // (the output of feature_linear is NOT saved: it is an affine function of h7, and the two weight gradients that would
+  //  need it or its gradient follow from G = d z9^T h7 — mlp_wgrad.h, wgrad_post_kernel)
   SNR_HD int64_t kib_per_tile() const {
-    return B::KS_PE + 8 * B::KS_H + 8 /*masks 0..7*/ + (use_viewdirs ? B::KS_DIR + B::KS_H + B::KS_H9 + 1 : 0);
+    return B::KS_PE + 8 * B::KS_H + 8 /*masks 0..7*/ + (use_viewdirs ? B::KS_DIR + B::KS_H9 + 1 : 0);
   }
   SNR_HD int64_t bytes() const { return n_tiles * kib_per_tile() * 1024; }
   // section starts, in KiB per tile (k_*) and in bytes (off_* = n_tiles * 1024 * k_*)
@@ -135,14 +137,12 @@ template <int P> struct ActLayout {
   SNR_HD int k_h(int i) const { return B::KS_PE + i * B::KS_H; }
   SNR_HD int k_mask(int i) const { return B::KS_PE + 8 * B::KS_H + i; }  // i in 0..7
   SNR_HD int k_dir() const { return B::KS_PE + 8 * B::KS_H + 8; }
-  SNR_HD int k_feat() const { return k_dir() + B::KS_DIR; }
-  SNR_HD int k_h9() const { return k_feat() + B::KS_H; }
+  SNR_HD int k_h9() const { return k_dir() + B::KS_DIR; }
   SNR_HD int k_mask9() const { return k_h9() + B::KS_H9; }
   SNR_HD int64_t off_pe() const { return 0; }
   SNR_HD int64_t off_h(int i) const { return n_tiles * 1024 * k_h(i); }
   SNR_HD int64_t off_mask(int i) const { return n_tiles * 1024 * k_mask(i); }
   SNR_HD int64_t off_dir() const { return n_tiles * 1024 * k_dir(); }
-  SNR_HD int64_t off_feat() const { return n_tiles * 1024 * k_feat(); }
   SNR_HD int64_t off_h9() const { return n_tiles * 1024 * k_h9(); }
   SNR_HD int64_t off_mask9() const { return n_tiles * 1024 * k_mask9(); }
 };

@@ -1,5 +1,18 @@
-// Weight-gradient pass of the fused NeRF MLP backward (gfx950): split-K kernel + reduce/scatter.
-// Included by mlp_bwd.hip.  See the header comment there for the overall backward structure.
+// Weight-gradient pass of the fused NeRF MLP backward (gfx950): split-K kernel + reduce/scatter + the
+// small dense products that replace two streamed jobs.  Included by mlp_bwd.hip.  See the header comment
+// there for the overall backward structure.
+//
+// Bytes are what this pass costs (it streams saved tensors once from HBM and is bound by that stream), so
+// the job list is built to read as few of them as possible:
+//   * jobs that share an operand are merged — one job's A side or B side may be the concatenation of two saved
+//     sections (d z5 against [pe | h4]; [d z9 | d out] against [h7 | dir]), so the shared section is read once;
+//   * feature_linear's output `feat` = W_f h7 + b_f has no activation, and neither has its gradient
+//     d feat = W_v[:, :256]^T d z9.  With G = sum_s d z9[s] (x) h7[s] and s9 = sum_s d z9[s]
+//         dW_views[:, :256] = sum_s d z9 (x) feat   = G W_f^T + s9 (x) b_f
+//         dW_feat           = sum_s d feat (x) h7   = W_v[:, :256]^T G         db_feat = W_v[:, :256]^T s9
+//     so neither `feat` nor `d feat` is written by the chain kernels or read here: one 128 x 256 job (G) and two
+//     tiny dense products (wgrad_post_kernel) replace a 256 x 256 and a 128 x 256 job.
+// Per sample (bf16, viewdirs) the pass reads 9.1 KB instead of 11.4 KB, and forward / dgrad write 0.5 KB less each.
 #pragma once
 #include <stdlib.h>
 
@@ -9,7 +22,7 @@
 
 namespace snr {
 
-// backward scratch: d z sections ([n_tiles][ks KiB], like ActLayout) followed by wgrad partials
+// backward scratch: d z sections ([n_tiles][ks KiB], like ActLayout) followed by wgrad partials and the G block
 template <int P> struct WsLayout {
   using B = Blob<P>;
   int64_t n_tiles;
@@ -17,63 +30,77 @@ template <int P> struct WsLayout {
   SNR_HD WsLayout(int64_t n_samples, int vd_) : n_tiles(padded_tiles<P>(n_samples)), vd(vd_) {}
   SNR_HD int k_dout() const { return 0; }
   SNR_HD int k_dz(int i) const { return 1 + i * B::KS_H; }  // i in 0..7
-  SNR_HD int k_dfeat() const { return 1 + 8 * B::KS_H; }
-  SNR_HD int k_dz9() const { return k_dfeat() + B::KS_H; }
+  SNR_HD int k_dz9() const { return 1 + 8 * B::KS_H; }
   SNR_HD int64_t off_dout() const { return 0; }
   SNR_HD int64_t off_dz(int i) const { return n_tiles * 1024 * k_dz(i); }
-  SNR_HD int64_t off_dfeat() const { return n_tiles * 1024 * k_dfeat(); }
   SNR_HD int64_t off_dz9() const { return n_tiles * 1024 * k_dz9(); }
-  SNR_HD int64_t dz_bytes() const {
-    return n_tiles * 1024 * (1 + 8 * (int64_t)B::KS_H + (vd ? B::KS_H + B::KS_H9 : 0));
-  }
+  SNR_HD int64_t dz_bytes() const { return n_tiles * 1024 * (1 + 8 * (int64_t)B::KS_H + (vd ? B::KS_H9 : 0)); }
 };
 
-// One job = one (d z section) x (activation section) product = the gradient of one weight block.
+// G[128][256] (true neuron order) followed by s9[128]: floats behind the split-K partials
+constexpr int kPostG = (kW / 2) * kW, kPostFloats = kPostG + kW / 2;
+
+// One job = (one or two d z sections) x (one or two activation sections): a block of weight gradients.
+struct WgradSec { int64_t off; int ks; };   // byte offset of the [n_tiles][ks KiB] section, KiB per tile
 struct WgradJob {
-  int64_t a_off, b_off;     // byte offsets of the [n_tiles][ks KiB] sections (A in ws, B in act)
-  int a_ks, b_ks;           // KiB per tile
+  WgradSec a[2], b[2];      // A side (rows) lives in ws, B side (columns) in act; ks == 0 = unused
+  int a_ks, b_ks;           // KiB per tile of each side (sum over its sections)
   int nta, ntb;             // 32-row / 32-column output tiles
-  int a_kind, b_kind;       // SrcKind of the k-slot order (for the reduce scatter)
-  int w_off, ld, col_off;   // destination weight matrix
-  int row_off, rows_valid;  // OUT sources: weight row = channel - row_off
-  int cols_valid;           // valid true columns of the B side
-  int bias_off;             // destination bias or -1
   int split_begin, n_splits;
   int64_t part_off;         // float offset of this job's partials [n_splits][nta*32][ntb*32]
-  int64_t bias_part_off;    // ... and of its bias partials [n_splits][nta*32]
+  int64_t bias_part_off;    // ... and of its row sums [n_splits][nta*32]
 };
-constexpr int kMaxJobs = 16;
+// One output = a rectangle of a job's partial sums and where it goes in the parameter gradient.
+struct WgradOut {
+  int job;
+  int row0, rows, col0, cols;   // in k-slots of the job's A / B side; cols == 0: row sums (bias) only
+  int a_kind, b_kind;           // SrcKind of the slot order inside the rectangle (relative to row0 / col0)
+  int L;                        // multires of an encoding B side
+  int w_off, ld, col_off;       // destination weight matrix (float offsets)
+  int row_off, rows_valid;      // OUT sources: weight row = channel - row_off
+  int cols_valid;               // valid true columns of the B side
+  int bias_off;                 // destination bias or -1
+  int to_scratch;               // 1: destination offsets are relative to the G block (stored, never accumulated)
+};
+constexpr int kMaxJobs = 12, kMaxOuts = 20;
 struct WgradArgs {
-  int n_jobs;
+  int n_jobs, n_outs;
   WgradJob job[kMaxJobs];
+  WgradOut out[kMaxOuts];
   const char* act;
   const char* ws;
   float* part;
+  float* post;      // G block (kPostFloats) or null
   int64_t n_tiles;
-  int L_pts, L_dir;
 };
 
-// LDS ring of whole tiles (A section | B section of 32 samples).  bf16: 5 slots x 32 KiB (all 160 KiB of
-// the CU), 4 tiles in flight — 0.421 ms vs 0.443 ms with 4 slots / 3 in flight at 196 608 samples;
-// fp32: 2 slots x 64 KiB, 1 in flight.
+// LDS ring of whole tiles (A sections | B sections of 32 samples), sized by the job's tile: as many slots as fit
+// into the CU's 160 KiB, at most 5 (bf16: 32 KiB tiles -> 5 slots, 4 tiles in flight — 0.421 ms vs 0.443 ms with 4 / 3
+// at 196 608 samples; the 36 KiB tile of the merged skip-layer job -> 4 slots) / 2 (fp32: 64 KiB tiles, 1 in flight).
 template <int P> struct WgradCfg;
-template <> struct WgradCfg<kBF16> { static constexpr int RING = 5, DEPTH = 4; };
-template <> struct WgradCfg<kFP32> { static constexpr int RING = 2, DEPTH = 1; };
+template <> struct WgradCfg<kBF16> { static constexpr int RING = 5; };
+template <> struct WgradCfg<kFP32> { static constexpr int RING = 2; };
+constexpr int kLdsBytes = 160 * 1024;
+template <int P> SNR_HD int wgrad_ring(int per_tile) {
+  const int fit = kLdsBytes / (per_tile * 1024);
+  return fit < WgradCfg<P>::RING ? fit : WgradCfg<P>::RING;
+}
 
 // Everything a workgroup needs from its job, copied to registers once (the job table lives in the
 // kernarg segment; indexing it inside the hot loop costs a scalar load per use).
-struct WgradLocal {
-  const char* a_base;
-  const char* b_base;
+struct WgradLocal {   // (scalar members, no arrays: a select between two array elements becomes a run-time index
+                      //  and drags the whole struct into scratch memory)
+  const char *a0_base, *a1_base, *b0_base, *b1_base;
+  int a0_ks, a1_ks, b0_ks, b1_ks;
   float* part;
-  float* bias_part;  // null = no bias
+  float* bias_part;
   int a_ks, b_ks, ntb_total;
   int64_t t0, t1;    // tile range of this split
 };
 
 // 8 waves per workgroup = two per SIMD: while one wave sits in the vector-memory issue queue (DMA)
 // or at a wait, its SIMD partner keeps the matrix pipe busy.  Each wave owns one 32-row tile of the
-// output (128 accumulator registers) across all column tiles.
+// output (up to 160 accumulator registers) across all column tiles.
 constexpr int kWgradWaves = 8;
 #ifndef SNR_WGRAD_AUX
 #define SNR_WGRAD_AUX 0
@@ -82,7 +109,7 @@ constexpr int kWgradWaves = 8;
 #if defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 2
 #define SNR_WGRAD_ISSUE(k) (void)0
 #else
-#define SNR_WGRAD_ISSUE(k) issue_piece(islot, (k))
+#define SNR_WGRAD_ISSUE(k) issue_piece(islot, std::integral_constant<int, (k)>{})
 #endif
 
 // The whole life of one wave of a workgroup for a job whose output is NTB column tiles wide, of which
@@ -103,34 +130,52 @@ template <int N> __device__ __forceinline__ void tr_wait(bf16x4& a, bf16x4& b, b
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N < 15 ? N : 15));
 }
 
-template <int P, int NTB, int NX, int NI>
+template <int P, int NTB, int NX, int NI, int R>
 __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int wave, int lane, int ta0, int ni) {
   using M = Mma<P>;
   using Frag = typename M::Frag;
-  constexpr int R = WgradCfg<P>::RING, D = WgradCfg<P>::DEPTH;
-  constexpr int SLOT = 2 * Blob<P>::KS_H * 1024;
+  constexpr int D = R - 1;
   const int a_ks = L.a_ks, b_ks = L.b_ks;
   const int per_tile = a_ks + b_ks;
-  const bool do_bias = L.bias_part != nullptr;
+  const int SLOT = per_tile * 1024;
 
   // ---- DMA pieces of this wave: wave + 8k (clamped), source pointer advances one tile per tile ----
+  // The section fields are copied into opaque scalars first: a `cond ? L.x : L.y` on the struct is turned into a load
+  // from a selected ADDRESS before this function is inlined, which keeps the whole struct in scratch memory afterwards
+  // (and every scratch load is a vector-memory load the compiler drains the DMA queue for).
+  const char *a0b = L.a0_base, *a1b = L.a1_base, *b0b = L.b0_base, *b1b = L.b1_base;
+  int a0k = L.a0_ks, a1k = L.a1_ks, b0k = L.b0_ks, b1k = L.b1_ks;
+  asm volatile("" : "+s"(a0b), "+s"(a1b), "+s"(b0b), "+s"(b1b), "+s"(a0k), "+s"(a1k), "+s"(b0k), "+s"(b1k));
   const char* src[NI];
   int lds_off[NI], stride[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     int p = wave + kWgradWaves * k;
     if (p >= per_tile) p = per_tile - 1;
+    // which section of which side piece p belongs to (A sections first, then B sections)
     const bool isA = p < a_ks;
-    src[k] = (isA ? L.a_base + (L.t0 * a_ks + p) * 1024 : L.b_base + (L.t0 * b_ks + (p - a_ks)) * 1024) + lane * 16;
-    stride[k] = (isA ? a_ks : b_ks) * 1024;
+    int q = isA ? p : p - a_ks;
+    const int ks0 = isA ? a0k : b0k;
+    const bool second = q >= ks0;
+    if (second) q -= ks0;
+    const char* base = isA ? (second ? a1b : a0b) : (second ? b1b : b0b);
+    const int ks = isA ? (second ? a1k : a0k) : (second ? b1k : b0k);
+    src[k] = base + (L.t0 * ks + q) * 1024 + lane * 16;
+    stride[k] = ks * 1024;
     lds_off[k] = p * 1024;
   }
   int64_t src_tile = L.t0;
-  auto issue_piece = [&](int slot, int k) {
-    // (non-temporal aux = 2 measured no faster: 0.76 vs 0.74 ms)
-    // (s_nop: no LDS read may sit in the cycle in front of an LDS-DMA — mlp_device.h, Pipe::issue_one)
-    if (k < ni) asm volatile("s_nop 0");
-    if (k < ni) __builtin_amdgcn_global_load_lds(src[k], SNR_LDS(smem + slot * SLOT + lds_off[k]), 16, 0, SNR_WGRAD_AUX);
+  // Piece indices are compile-time constants everywhere: a run-time index into src[] / lds_off[] would put the arrays
+  // into scratch memory, and every scratch load is a vector-memory load the compiler waits for with vmcnt(0) — i.e. it
+  // would drain the DMA queue.
+  auto issue_piece = [&](int slot, auto K_) {
+    constexpr int k = decltype(K_)::value;
+    if constexpr (k < NI) {
+      // (non-temporal aux = 2 measured no faster: 0.76 vs 0.74 ms)
+      // (s_nop: no LDS read may sit in the cycle in front of an LDS-DMA — mlp_device.h, Pipe::issue_one)
+      if (k < ni) asm volatile("s_nop 0");
+      if (k < ni) __builtin_amdgcn_global_load_lds(src[k], SNR_LDS(smem + slot * SLOT + lds_off[k]), 16, 0, SNR_WGRAD_AUX);
+    }
   };
   auto advance = [&]() {   // past the end the last tile is re-loaded: the instruction count stays uniform
 #if defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 4   // timing experiment: the stream re-reads one tile (L2 hits)
@@ -160,7 +205,9 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
   // block parity bh the physical row is 8gg + (4q ^ 4bh) + r4.  Offset within a tile section:
   //   (2*tI + bh)*1024 + row*32 + c4*8 + half*512 ; everything but tI and half is per-lane constant.
   const int G = lane >> 4, ip = lane & 15, gg = G >> 1, bh = G & 1, c4 = ip & 3, r4 = ip >> 2;
-  const int bhA = a_ks == 1 ? 0 : bh;   // 16-wide OUT sections have one block: lanes of block 1 re-read block 0
+  // a 16-wide OUT section closes the A side with a single block: lanes of block 1 re-read block 0 (rows 16..31 of that
+  // output tile are duplicates nobody reads)
+  const int bhA = (2 * ta0 + 1 < a_ks) ? bh : 0;
   int offA[2], offB[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -171,8 +218,7 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
 
 #if !(defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 2)
   for (int d = 0; d < D; ++d) {
-#pragma unroll
-    for (int k = 0; k < NI; ++k) issue_piece(d % R, k);
+    static_for<0, NI>([&](auto K_) { issue_piece(d % R, K_); });
     advance();
   }
 #endif
@@ -187,7 +233,10 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
     __builtin_amdgcn_s_barrier();                           // same for everybody: slot of tile-1 is free
     asm volatile("" ::: "memory");
 #endif
-    int kq = 0;   // DMA pieces of tile + D issued so far
+    // DMA pieces of tile + D are dripped between the MFMAs: bf16 one behind every MFMA (every second one from 8 column
+    // tiles on), fp32 one behind every k-step
+    constexpr int kPerHalf = NTB < 8 ? NTB : NTB / 2;
+    constexpr int kDripped = NX == 0 ? 0 : (P == kBF16 ? (2 * kPerHalf < NI ? 2 * kPerHalf : NI) : (16 < NI ? 16 : NI));
     if constexpr (NX > 0) {
       char* sbase = smem + slot * SLOT;
       if constexpr (P == kBF16) {
@@ -213,16 +262,14 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
             if constexpr (y == 0) {
               tr_wait<2 * (NTB - 1)>(alo, ahi, blo[0], bhi[0]);
               fa = Frag{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
-              if (do_bias) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bsum += (float)fa[e];
-              }
+              for (int e = 0; e < 8; ++e) bsum += (float)fa[e];
             } else {
               tr_wait<2 * (NTB - 1 - y)>(blo[y], bhi[y]);
             }
             const Frag fb = Frag{blo[y][0], blo[y][1], blo[y][2], blo[y][3], bhi[y][0], bhi[y][1], bhi[y][2], bhi[y][3]};
             acc[0][y] = M::mma(fa, fb, acc[0][y]);
-            if ((NTB < 8 || (y & 1)) && kq < NI) { SNR_WGRAD_ISSUE(kq); ++kq; }
+            if constexpr (NTB < 8 || (y & 1)) { SNR_WGRAD_ISSUE(half * kPerHalf + (NTB < 8 ? y : y / 2)); }
           });
         });
       } else {
@@ -234,23 +281,21 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
           if (q >= ks) q = ks - 1;
           return sec[(q * 32 + sidx) * 8 + (i32 & 7)];
         };
-#pragma unroll 4
-        for (int ks2 = 0; ks2 < 16; ++ks2) {
+        static_for<0, 16>([&](auto KS_) {
+          constexpr int ks2 = decltype(KS_)::value;
           const int sidx = 2 * ks2 + g32;
           const float fa = elem(fa_base, a_ks, ta0, sidx);
-          if (do_bias) bsum += fa;
+          bsum += fa;
 #pragma unroll
           for (int y = 0; y < NTB; ++y) {
             const float fb = elem(fb_base, b_ks, y, sidx);
             acc[0][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[0][y], 0, 0, 0);
           }
-          if (kq < NI) { SNR_WGRAD_ISSUE(kq); ++kq; }
-        }
+          SNR_WGRAD_ISSUE(ks2);
+        });
       }
     }
-#pragma unroll
-    for (int k = 0; k < NI; ++k)
-      if (k >= kq) { SNR_WGRAD_ISSUE(k); }
+    static_for<kDripped, NI>([&](auto K_) { SNR_WGRAD_ISSUE(decltype(K_)::value); });
 #if !(defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 2)
     advance();
 #endif
@@ -270,11 +315,9 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
         L.part[(int64_t)row * NB + 32 * y + i32] = acc[0][y][r];
       }
     }
-    if (do_bias) {
-      // lanes l and l^32 hold the two sample halves of the same neuron row (row = lane & 31)
-      const float bs = bsum + __shfl_xor(bsum, 32, 64);
-      if (lane < 32) L.bias_part[32 * ta0 + lane] = bs;
-    }
+    // lanes l and l^32 hold the two sample halves of the same neuron row (row = lane & 31)
+    const float bs = bsum + __shfl_xor(bsum, 32, 64);
+    if (lane < 32) L.bias_part[32 * ta0 + lane] = bs;
   }
 }
 
@@ -289,14 +332,16 @@ __global__ __launch_bounds__(64 * kWgradWaves) void mlp_wgrad_kernel(WgradArgs a
   const WgradJob& J = a.job[ji];
   const int split = blockIdx.x - J.split_begin;
   WgradLocal L;
-  L.a_base = a.ws + J.a_off;
-  L.b_base = a.act + J.b_off;
+  L.a0_base = a.ws + J.a[0].off; L.a0_ks = J.a[0].ks;
+  L.a1_base = a.ws + J.a[1].off; L.a1_ks = J.a[1].ks;
+  L.b0_base = a.act + J.b[0].off; L.b0_ks = J.b[0].ks;
+  L.b1_base = a.act + J.b[1].off; L.b1_ks = J.b[1].ks;
   L.a_ks = J.a_ks; L.b_ks = J.b_ks; L.ntb_total = J.ntb;
   L.t0 = a.n_tiles * split / J.n_splits;
   L.t1 = a.n_tiles * (split + 1) / J.n_splits;
   const int nta = J.nta, ntb = J.ntb;
   L.part = a.part + J.part_off + (int64_t)split * nta * 32 * ntb * 32;
-  L.bias_part = J.bias_off >= 0 ? a.part + J.bias_part_off + (int64_t)split * nta * 32 : nullptr;
+  L.bias_part = a.part + J.bias_part_off + (int64_t)split * nta * 32;
   const int ta0 = wave;
 #if defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 1   // timing experiment: DMA stream only
   const int nx = 0;
@@ -304,26 +349,34 @@ __global__ __launch_bounds__(64 * kWgradWaves) void mlp_wgrad_kernel(WgradArgs a
   const int nx = ta0 < nta ? 1 : 0;
 #endif
 
-  // shapes that occur (rows x cols in 32-tiles): 8x8 (256x256), 8x2 (x encodings), 4x8 / 4x1 (views
-  // layer), 1x8 / 1x4 (heads); ni = DMA instructions per wave per tile
-  const int ni = (J.a_ks + J.b_ks + kWgradWaves - 1) / kWgradWaves;
-#define SNR_RUN(NTB_, NX_, NI_) wgrad_run<P, NTB_, NX_, NI_>(L, smem, wave, lane, ta0, ni)
+  // shapes that occur (rows x cols in 32-tiles; KiB per tile -> DMA instructions per wave, ring slots), bf16 viewdirs:
+  //   8x2  (d z0 x pe; 20 -> 3, 5)      8x8 (d z_i x h_{i-1}; 32 -> 4, 5)     8x10 (d z5 x [pe | h4]; 36 -> 5, 4)
+  //   5x9  ([d z9 | d out] x [h7 | dir]; 27 -> 4, 5)          1x4 (d out x h9; 9 -> 2, 5)
+  //   without viewdirs: 1x8 (d out x h7; 17 -> 3, 5)
+  const int per_tile = J.a_ks + J.b_ks;
+  const int ni = (per_tile + kWgradWaves - 1) / kWgradWaves;
+#define SNR_RUN(NTB_, NX_, NI_, R_) wgrad_run<P, NTB_, NX_, NI_, R_>(L, smem, wave, lane, ta0, ni)
   if constexpr (P == kFP32) {   // one tile in flight: the wait immediate is 0 whatever ni is
-    if (nx == 0) SNR_RUN(1, 0, 8);
-    else if (ntb == 8) SNR_RUN(8, 1, 8);
-    else if (ntb == 4) SNR_RUN(4, 1, 8);
-    else if (ntb == 2) SNR_RUN(2, 1, 8);
-    else SNR_RUN(1, 1, 8);
+    if (nx == 0) SNR_RUN(1, 0, 8, 2);
+    else if (ntb == 9) SNR_RUN(9, 1, 8, 2);
+    else if (ntb == 8) SNR_RUN(8, 1, 8, 2);
+    else if (ntb == 4) SNR_RUN(4, 1, 8, 2);
+    else if (ntb == 2) SNR_RUN(2, 1, 8, 2);
+    else SNR_RUN(1, 1, 8, 2);
+  } else if (ni == 5) {
+    if (nx == 0) SNR_RUN(1, 0, 5, 4); else SNR_RUN(10, 1, 5, 4);
   } else if (ni == 4) {
-    if (nx == 0) SNR_RUN(1, 0, 4); else SNR_RUN(8, 1, 4);
+    if (nx == 0) SNR_RUN(1, 0, 4, 5);
+    else if (ntb == 9) SNR_RUN(9, 1, 4, 5);
+    else SNR_RUN(8, 1, 4, 5);
   } else if (ni == 3) {
-    if (nx == 0) SNR_RUN(1, 0, 3);
-    else if (ntb == 8) SNR_RUN(8, 1, 3);
-    else SNR_RUN(2, 1, 3);
+    if (nx == 0) SNR_RUN(1, 0, 3, 5);
+    else if (ntb == 8) SNR_RUN(8, 1, 3, 5);
+    else SNR_RUN(2, 1, 3, 5);
   } else {
-    if (nx == 0) SNR_RUN(1, 0, 2);
-    else if (ntb == 4) SNR_RUN(4, 1, 2);
-    else SNR_RUN(1, 1, 2);
+    if (nx == 0) SNR_RUN(1, 0, 2, 5);
+    else if (ntb == 4) SNR_RUN(4, 1, 2, 5);
+    else SNR_RUN(1, 1, 2, 5);
   }
 #undef SNR_RUN
 }
@@ -341,29 +394,30 @@ template <int P> __device__ __forceinline__ int slot_true_index(int kind, int x,
 
 template <int P>
 __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, int accumulate) {
-  // Every parameter element a job produces is produced by exactly one (job, row, column): without
-  // `accumulate` the result is stored, not added, and the gradient buffer needs no clearing first
+  // Every parameter element is produced by exactly one (output, row, column): without `accumulate` the result is
+  // stored, not added, and the gradient buffer needs no clearing first
   // (tests/test_gpu_kernels.py: test_mlp_backward_overwrites_every_element).
-  // blockIdx.y = job; a thread covers (row, 4 consecutive partial-sum columns); one extra thread per row does
+  // blockIdx.y = output; a thread covers (row, 4 consecutive partial-sum columns); one extra thread per row does
   // the bias.  16-byte loads, two independent accumulators per element.
-  const WgradJob& J = a.job[blockIdx.y];
-  const int NA = J.nta * 32, NB = J.ntb * 32, NQ = NB / 4;
+  const WgradOut& O = a.out[blockIdx.y];
+  const WgradJob& J = a.job[O.job];
+  const int NA = J.nta * 32, NB = J.ntb * 32, NQ = O.cols / 4;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)NA * (NQ + 1)) return;
+  if (idx >= (int64_t)O.rows * (NQ + 1)) return;
   const int ra = (int)(idx / (NQ + 1)), q = (int)(idx % (NQ + 1));
-  if (ra >= J.a_ks * 2 * Prec<P>::EPF) return;
-  const int n = slot_true_index<P>(J.a_kind, ra, 0) - (J.a_kind == SRC_OUT ? J.row_off : 0);
-  if (n < 0 || n >= J.rows_valid) return;
+  const int n = slot_true_index<P>(O.a_kind, ra, 0) - (O.a_kind == SRC_OUT ? O.row_off : 0);
+  if (n < 0 || n >= O.rows_valid) return;
+  float* dst = O.to_scratch ? a.post : grad;
+  const bool acc = accumulate && !O.to_scratch;
   if (q == NQ) {
-    if (J.bias_off < 0) return;
+    if (O.bias_off < 0) return;
     float s = 0.f;
-    for (int sp = 0; sp < J.n_splits; ++sp) s += a.part[J.bias_part_off + (int64_t)sp * NA + ra];
-    grad[J.bias_off + n] = accumulate ? grad[J.bias_off + n] + s : s;
+    for (int sp = 0; sp < J.n_splits; ++sp) s += a.part[J.bias_part_off + (int64_t)sp * NA + O.row0 + ra];
+    dst[O.bias_off + n] = acc ? dst[O.bias_off + n] + s : s;
     return;
   }
   const int cb = 4 * q;
-  if (cb >= J.b_ks * 2 * Prec<P>::EPF) return;
-  const float* p = a.part + J.part_off + (int64_t)ra * NB + cb;
+  const float* p = a.part + J.part_off + (int64_t)(O.row0 + ra) * NB + O.col0 + cb;
   const int64_t st = (int64_t)NA * NB;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   int sp = 0;
@@ -373,13 +427,104 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, i
   }
   if (sp < J.n_splits) s0 += *(const f32x4*)(p + sp * st);
   const f32x4 s = s0 + s1;
-  float* grow = grad + J.w_off + (int64_t)n * J.ld + J.col_off;
-  const int L = J.b_kind == SRC_ENC_DIR ? a.L_dir : a.L_pts;
+  float* grow = dst + O.w_off + (int64_t)n * O.ld + O.col_off;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int k = slot_true_index<P>(J.b_kind, cb + e, L);
-    if (k < 0 || k >= J.cols_valid) continue;
-    grow[k] = accumulate ? grow[k] + s[e] : s[e];
+    const int k = slot_true_index<P>(O.b_kind, cb + e, O.L);
+    if (k < 0 || k >= O.cols_valid) continue;
+    grow[k] = acc ? grow[k] + s[e] : s[e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// the two dense products behind G (header comment): exact fp32 MFMA, one workgroup of 4 waves per 32 x 32 output
+// tile, each wave a quarter of the contraction, summed through LDS.
+//   tiles  0..63 : dW_feat[j][k]        = sum_m Wv[m][j] G[m][k]                  (256 x 256, contraction 128)
+//   tiles 64..95 : dW_views[m][j < 256] = sum_k G[m][k] Wf[j][k] + s9[m] b_f[j]   (128 x 256, contraction 256)
+//   tile  96     : db_feat[j]           = sum_m Wv[m][j] s9[m]
+// P == bf16 rounds the two weight matrices to bf16 first: the forward and dgrad kernels evaluated the layers with the
+// rounded weights, and the products restate exactly those layers.
+// ------------------------------------------------------------------------------------------
+struct PostArgs {
+  const float* params;
+  const float* post;   // G [128][256], s9 [128]
+  float* grad;
+  int w_views, ld_views, w_feat, b_feat;   // float offsets in params / grad (ld_views = 256 + in_dir)
+  int accumulate;
+};
+
+template <int P> __device__ __forceinline__ float wround(float x) {
+  return P == kBF16 ? (float)(__bf16)x : x;
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void wgrad_post_kernel(PostArgs a) {
+  __shared__ float red[3][64][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const float* G = a.post;
+  const float* s9 = a.post + kPostG;
+  const float* Wv = a.params + a.w_views;
+  const float* Wf = a.params + a.w_feat;
+  const int t = blockIdx.x;
+  if (t == 96) {
+    const int j = tid;   // 256 threads
+    float s = 0.f;
+    for (int m = 0; m < kW / 2; ++m) s += wround<P>(Wv[(int64_t)m * a.ld_views + j]) * s9[m];
+    float* d = a.grad + a.b_feat + j;
+    *d = a.accumulate ? *d + s : s;
+    return;
+  }
+  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int r0, c0;   // output tile origin
+  if (t < 64) {
+    // C[j][k] = sum_m A[j][m] B[m][k], A[j][m] = Wv[m][j0 + j], B[m][k] = G[m][k0 + k]; m = 32 * wave + 2 * s + h
+    r0 = 32 * (t >> 3); c0 = 32 * (t & 7);
+    const int m0 = 32 * wave;
+#pragma unroll 8
+    for (int s = 0; s < 16; ++s) {
+      const int m = m0 + 2 * s + h;
+      const float av = wround<P>(Wv[(int64_t)m * a.ld_views + r0 + i]);
+      const float bv = G[m * kW + c0 + i];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  } else {
+    // C[m][j] = sum_k A[m][k] B[k][j], A[m][k] = G[m0 + m][k], B[k][j] = Wf[j0 + j][k]; both contiguous in k:
+    // a lane loads 4 consecutive k (16 B) and spends them on 4 MFMA steps — step e of a group uses k = base + 4 h + e
+    // on both operands
+    const int tt = t - 64;
+    r0 = 32 * (tt >> 3); c0 = 32 * (tt & 7);
+    const int k0 = 64 * wave;
+    const float* ga = G + (int64_t)(r0 + i) * kW + k0 + 4 * h;
+    const float* wb = Wf + (int64_t)(c0 + i) * kW + k0 + 4 * h;
+#pragma unroll 4
+    for (int s = 0; s < 8; ++s) {
+      const f32x4 av = *(const f32x4*)(ga + 8 * s);
+      const f32x4 bv = *(const f32x4*)(wb + 8 * s);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wround<P>(bv[e]), acc, 0, 0, 0);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][lane][r] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[r] + red[0][lane][r] + red[1][lane][r] + red[2][lane][r];
+      const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * h, col = c0 + i;
+      float* d;
+      float val = v;
+      if (t < 64) {
+        d = a.grad + a.w_feat + (int64_t)row * kW + col;
+      } else {
+        val += s9[row] * a.params[a.b_feat + col];
+        d = a.grad + a.w_views + (int64_t)row * a.ld_views + col;
+      }
+      *d = a.accumulate ? *d + val : val;
+    }
   }
 }
 
@@ -389,47 +534,76 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, i
 template <int P>
 static WgradArgs make_jobs(const snr_mlp_config* c, int64_t n_samples, int64_t* part_floats, int* total_splits) {
   using B = Blob<P>;
+  constexpr int SPF = 2 * Prec<P>::EPF;   // k-slots per frag
   const int vd = c->use_viewdirs;
   const ParamLayout L = make_param_layout(c->multires, c->multires_views, vd, c->out_ch, c->i_embed == -1);
   const ActLayout<P> AL(n_samples, vd);
   const WsLayout<P> WL(n_samples, vd);
   WgradArgs A{};
   A.n_tiles = AL.n_tiles;
-  A.L_pts = c->i_embed == -1 ? 0 : c->multires;
-  A.L_dir = c->i_embed == -1 ? 0 : c->multires_views;
-  int n = 0;
-  auto add = [&](int64_t a_off, int a_ks, int a_kind, int nta, int64_t b_off, int b_ks, int b_kind, int ntb,
-                 int64_t w_off, int ld, int col_off, int row_off, int rows_valid, int cols_valid, int64_t bias_off) {
-    WgradJob& J = A.job[n++];
-    J.a_off = a_off; J.a_ks = a_ks; J.a_kind = a_kind; J.nta = nta;
-    J.b_off = b_off; J.b_ks = b_ks; J.b_kind = b_kind; J.ntb = ntb;
-    J.w_off = (int)w_off; J.ld = ld; J.col_off = col_off; J.row_off = row_off; J.rows_valid = rows_valid;
-    J.cols_valid = cols_valid; J.bias_off = (int)bias_off;
+  const int L_pts = c->i_embed == -1 ? 0 : c->multires, L_dir = c->i_embed == -1 ? 0 : c->multires_views;
+  int n = 0, no = 0;
+  const WgradSec none{0, 0};
+  auto job = [&](WgradSec a0, WgradSec a1, WgradSec b0, WgradSec b1) {
+    WgradJob& J = A.job[n];
+    J.a[0] = a0; J.a[1] = a1; J.b[0] = b0; J.b[1] = b1;
+    J.a_ks = a0.ks + a1.ks; J.b_ks = b0.ks + b1.ks;
+    J.nta = (J.a_ks * SPF + 31) / 32; J.ntb = (J.b_ks * SPF + 31) / 32;
+    return n++;
+  };
+  auto out = [&](int j, int row0, int rows, int a_kind, int col0, int cols, int b_kind, int Lenc, int64_t w_off, int ld,
+                 int col_off, int row_off, int rows_valid, int cols_valid, int64_t bias_off, int to_scratch = 0) {
+    WgradOut& O = A.out[no++];
+    O.job = j; O.row0 = row0; O.rows = rows; O.a_kind = a_kind; O.col0 = col0; O.cols = cols; O.b_kind = b_kind;
+    O.L = Lenc; O.w_off = (int)w_off; O.ld = ld; O.col_off = col_off; O.row_off = row_off; O.rows_valid = rows_valid;
+    O.cols_valid = cols_valid; O.bias_off = (int)bias_off; O.to_scratch = to_scratch;
   };
   const int ip = L.in_pts;
-  add(WL.off_dz(0), B::KS_H, SRC_H, 8, AL.off_pe(), B::KS_PE, SRC_ENC_PTS, 2, L.w_pts[0], ip, 0, 0, kW, ip, L.b_pts[0]);
+  const int SH = B::KS_H * SPF, SPE = B::KS_PE * SPF, SDIR = B::KS_DIR * SPF, SH9 = B::KS_H9 * SPF;   // slots per section
+  const WgradSec pe{AL.off_pe(), B::KS_PE};
+  auto dz = [&](int i) { return WgradSec{WL.off_dz(i), B::KS_H}; };
+  auto h = [&](int i) { return WgradSec{AL.off_h(i), B::KS_H}; };
+  // merged skip-layer job: its 36 KiB bf16 tile still leaves a 4-slot ring; fp32 (72 KiB tiles, 9 DMA instructions per
+  // wave) keeps the two jobs apart
+  const bool merge5 = P == kBF16;
+  {
+    const int j = job(dz(0), none, pe, none);
+    out(j, 0, SH, SRC_H, 0, SPE, SRC_ENC_PTS, L_pts, L.w_pts[0], ip, 0, 0, kW, ip, L.b_pts[0]);
+  }
   for (int i = 1; i < 8; ++i) {
     if (i == kSkip + 1) {
-      add(WL.off_dz(i), B::KS_H, SRC_H, 8, AL.off_pe(), B::KS_PE, SRC_ENC_PTS, 2, L.w_pts[i], kW + ip, 0, 0, kW, ip,
-          L.b_pts[i]);
-      add(WL.off_dz(i), B::KS_H, SRC_H, 8, AL.off_h(i - 1), B::KS_H, SRC_H, 8, L.w_pts[i], kW + ip, ip, 0, kW, kW, -1);
+      if (merge5) {
+        const int j = job(dz(i), none, pe, h(i - 1));
+        out(j, 0, SH, SRC_H, 0, SPE, SRC_ENC_PTS, L_pts, L.w_pts[i], kW + ip, 0, 0, kW, ip, L.b_pts[i]);
+        out(j, 0, SH, SRC_H, SPE, SH, SRC_H, 0, L.w_pts[i], kW + ip, ip, 0, kW, kW, -1);
+      } else {
+        int j = job(dz(i), none, pe, none);
+        out(j, 0, SH, SRC_H, 0, SPE, SRC_ENC_PTS, L_pts, L.w_pts[i], kW + ip, 0, 0, kW, ip, L.b_pts[i]);
+        j = job(dz(i), none, h(i - 1), none);
+        out(j, 0, SH, SRC_H, 0, SH, SRC_H, 0, L.w_pts[i], kW + ip, ip, 0, kW, kW, -1);
+      }
     } else {
-      add(WL.off_dz(i), B::KS_H, SRC_H, 8, AL.off_h(i - 1), B::KS_H, SRC_H, 8, L.w_pts[i], kW, 0, 0, kW, kW, L.b_pts[i]);
+      const int j = job(dz(i), none, h(i - 1), none);
+      out(j, 0, SH, SRC_H, 0, SH, SRC_H, 0, L.w_pts[i], kW, 0, 0, kW, kW, L.b_pts[i]);
     }
   }
+  const WgradSec dout{WL.off_dout(), 1};
   if (vd) {
-    add(WL.off_dfeat(), B::KS_H, SRC_H, 8, AL.off_h(7), B::KS_H, SRC_H, 8, L.w_feat, kW, 0, 0, kW, kW, L.b_feat);
-    add(WL.off_dout(), 1, SRC_OUT, 1, AL.off_h(7), B::KS_H, SRC_H, 8, L.w_alpha, kW, 0, 3, 1, kW, L.b_alpha);
-    add(WL.off_dz9(), B::KS_H9, SRC_H, 4, AL.off_feat(), B::KS_H, SRC_H, 8, L.w_views, kW + L.in_dir, 0, 0, kW / 2, kW,
-        L.b_views);
-    if (L.in_dir > 0)
-      add(WL.off_dz9(), B::KS_H9, SRC_H, 4, AL.off_dir(), B::KS_DIR, SRC_ENC_DIR, 1, L.w_views, kW + L.in_dir, kW, 0,
-          kW / 2, L.in_dir, -1);
-    add(WL.off_dout(), 1, SRC_OUT, 1, AL.off_h9(), B::KS_H9, SRC_H, 4, L.w_rgb, kW / 2, 0, 0, 3, kW / 2, L.b_rgb);
+    // [d z9 | d out] x [h7 | dir]: G (+ s9) to the scratch block, db_views, dW_views[:, 256:], dW_alpha (+ db_alpha);
+    // the d out x dir corner is computed and ignored
+    const WgradSec dz9{WL.off_dz9(), B::KS_H9}, dir{AL.off_dir(), B::KS_DIR}, h9{AL.off_h9(), B::KS_H9};
+    int j = job(dz9, dout, h(7), dir);
+    out(j, 0, SH9, SRC_H, 0, SH, SRC_H, 0, 0, kW, 0, 0, kW / 2, kW, kPostG, 1);
+    out(j, 0, SH9, SRC_H, 0, 0, SRC_H, 0, 0, 0, 0, 0, kW / 2, 0, L.b_views);
+    out(j, 0, SH9, SRC_H, SH, SDIR, SRC_ENC_DIR, L_dir, L.w_views, kW + L.in_dir, kW, 0, kW / 2, L.in_dir, -1);
+    out(j, SH9, SPF, SRC_OUT, 0, SH, SRC_H, 0, L.w_alpha, kW, 0, 3, 1, kW, L.b_alpha);
+    j = job(dout, none, h9, none);
+    out(j, 0, SPF, SRC_OUT, 0, SH9, SRC_H, 0, L.w_rgb, kW / 2, 0, 0, 3, kW / 2, L.b_rgb);
   } else {
-    add(WL.off_dout(), 1, SRC_OUT, 1, AL.off_h(7), B::KS_H, SRC_H, 8, L.w_out, kW, 0, 0, c->out_ch, kW, L.b_out);
+    const int j = job(dout, none, h(7), none);
+    out(j, 0, SPF, SRC_OUT, 0, SH, SRC_H, 0, L.w_out, kW, 0, 0, c->out_ch, kW, L.b_out);
   }
-  A.n_jobs = n;
+  A.n_jobs = n; A.n_outs = no;
   // split-K: the kernel streams saved activations once and is bound by that stream, so every workgroup
   // gets the same number of bytes: job i receives target * bytes_i / bytes workgroups, apportioned by
   // largest remainder so that the total is exactly one workgroup per CU — measured on MI355X (bench

@@ -83,6 +83,7 @@ class NeRF(nn.Module):
         self._packed = None
         self._packed_key = None
         self.pack_generation = 0   # bumped on every (in-place) re-pack; autograd contexts check it (ops._Mlp)
+        self.weights_generation = 0   # bumped by mark_weights_changed() (writes the version counter does not see)
 
     # ---- flat <-> named views --------------------------------------------------------------
     def named_views(self, flat=None):
@@ -162,6 +163,7 @@ class NeRF(nn.Module):
     def mark_weights_changed(self):
         """call after writing ``flat`` through a raw pointer (in-place torch ops are detected by version)"""
         self._packed_key = None
+        self.weights_generation += 1
 
     def set_precision(self, precision):
         self.precision = precision

@@ -240,6 +240,7 @@ class _Mlp(torch.autograd.Function):
         # the packed blob is re-packed IN PLACE when the parameters or the precision change: remember which pack this
         # graph was recorded against
         ctx.pack_gen, ctx.cfg_key = net.pack_generation, cfg.key()
+        ctx.flat_key = (flat._version, net.weights_generation)
         ctx.set_materialize_grads(False)
         return raw
 
@@ -254,7 +255,8 @@ class _Mlp(torch.autograd.Function):
         if ctx.act is None:
             raise RuntimeError("the saved activations of this MLP evaluation were released by its first backward "
                                "(retain_graph / a second backward through the same forward is not supported)")
-        if net.pack_generation != ctx.pack_gen or cfg.key() != ctx.cfg_key:
+        if (net.pack_generation != ctx.pack_gen or cfg.key() != ctx.cfg_key
+                or (net.flat._version, net.weights_generation) != ctx.flat_key):
             raise RuntimeError("the network's packed weights changed between forward and backward (optimizer step, "
                                "load_state_dict or set_precision in between): re-run the forward")
         g = torch.empty_like(net.flat)
@@ -262,8 +264,8 @@ class _Mlp(torch.autograd.Function):
         if ws_bytes <= 0:
             check(int(ws_bytes), "snr_mlp_bwd_ws_bytes")
         ws = torch.empty(ws_bytes, device=g.device, dtype=torch.uint8)
-        check(lib.snr_mlp_backward(cfg, ptr(ctx.packed), ptr(f32c(d_raw)), n, ptr(ctx.act), ptr(ws), ptr(g), 0,
-                                   stream()), "snr_mlp_backward")
+        check(lib.snr_mlp_backward(cfg, ptr(ctx.packed), ptr(net.flat.detach()), ptr(f32c(d_raw)), n, ptr(ctx.act),
+                                   ptr(ws), ptr(g), 0, stream()), "snr_mlp_backward")
         ctx.act = None
         return g, None, None, None, None, None, None, None
 

@@ -324,10 +324,10 @@ def test_mlp_backward_overwrites_every_element(S, vd, precision):
     d_raw = torch.from_numpy(rs.normal(size=(n, cfg.out_ch)).astype(np.float32)).cuda()
     ws = torch.empty(lib.snr_mlp_bwd_ws_bytes(cfg, n), dtype=torch.uint8, device="cuda")
     g = torch.full_like(net.flat.data, float("nan"))
-    L.check(lib.snr_mlp_backward(cfg, L.ptr(packed), L.ptr(d_raw), n, L.ptr(act), L.ptr(ws), L.ptr(g), 0, L.stream()), "bwd")
+    L.check(lib.snr_mlp_backward(cfg, L.ptr(packed), L.ptr(net.flat.detach()), L.ptr(d_raw), n, L.ptr(act), L.ptr(ws), L.ptr(g), 0, L.stream()), "bwd")
     assert torch.isfinite(g).all(), int((~torch.isfinite(g)).sum())
     g2 = g.clone()
-    L.check(lib.snr_mlp_backward(cfg, L.ptr(packed), L.ptr(d_raw), n, L.ptr(act), L.ptr(ws), L.ptr(g2), 1, L.stream()), "bwd")
+    L.check(lib.snr_mlp_backward(cfg, L.ptr(packed), L.ptr(net.flat.detach()), L.ptr(d_raw), n, L.ptr(act), L.ptr(ws), L.ptr(g2), 1, L.stream()), "bwd")
     close(g2, 2 * g, atol=1e-6 * float(g.abs().max()), rtol=1e-6)
 
 

@@ -243,3 +243,87 @@ def test_render_backward_matches_reference_grads(S, name):
             assert rel < tol, f"{pfx}{k}: relative L2 error {rel:.3e}"
             nrm = float(g[pfx + k + ".norm"])
             assert abs(float(gr.double().norm()) / nrm - 1) < tol, f"{pfx}{k}: norm"
+
+
+# ---------------------------------------------------------------------------------------------
+# the remaining ray-preparation branches of render() (run_nerf.py:117-153) — all on the packing kernel
+# ---------------------------------------------------------------------------------------------
+def _coarse_setup(S, vd=True):
+    from oracle import nerf_oracle as O
+    sd = O.make_wild_params(seed=21, use_viewdirs=vd, output_ch=4, input_ch_views=27 if vd else 0)
+    net = S.NeRF(input_ch=63, input_ch_views=27 if vd else 0, use_viewdirs=vd, output_ch=4, precision="fp32").cuda()
+    net.load_state_dict(sd)
+
+    def q(inputs, viewdirs, network_fn):
+        return S.run_network(inputs, viewdirs, network_fn)
+    q._snr_fused = True
+    kw = dict(network_query_fn=q, perturb=0., N_importance=0, network_fine=None, N_samples=64, network_fn=net,
+              use_viewdirs=vd, white_bkgd=False, raw_noise_std=0.)
+    okw = dict(sd_coarse=sd, sd_fine=None, N_samples=64, N_importance=0, perturb=0., white_bkgd=False, use_viewdirs=vd)
+    return O, kw, okw
+
+
+def _cmp_maps(got, ref):
+    close(got[0], ref[0], atol=2e-4, msg="rgb"); close(got[2], ref[2], atol=2e-4, msg="acc")
+    close(got[3], ref[3], rtol=1e-3, atol=2e-4, msg="depth"); close(got[1], ref[1], rtol=1e-3, atol=1e-4, msg="disp")
+    close(got[4]["z_vals"], ref[4]["z_vals"], atol=1e-6, msg="z_vals")
+
+
+@pytest.mark.parametrize("ndc", [False, True])
+def test_render_with_c2w_staticcam(S, ndc):
+    """rays of one camera, viewing directions of another (run_nerf.py:128-135): frame and patch"""
+    O, kw, okw = _coarse_setup(S)
+    H, W, f = 10, 12, 14.0
+    c2w = torch.eye(4)[:3, :4].clone(); c2w[:, 3] = torch.tensor([0.1, -0.2, 3.0])
+    rot = torch.tensor([[0.96, 0., 0.28], [0., 1., 0.], [-0.28, 0., 0.96]])
+    c2w_s = torch.cat([rot, torch.tensor([[0.3], [0.1], [2.5]])], 1)
+    nf = dict(near=0., far=1.) if ndc else dict(near=1.5, far=5.0)
+    for patch in (None, (2, 3, 5, 6)):
+        # the reference re-generates the WHOLE static-camera frame even in patch mode (get_rays at :133), so a patch
+        # with c2w_staticcam only works when the patch is the frame: exercise the patch without it
+        extra = dict(c2w_staticcam=c2w_s.cuda()) if patch is None else {}
+        oextra = dict(c2w_staticcam=c2w_s) if patch is None else {}
+        with torch.no_grad():
+            got = S.render(H, W, f, c2w=c2w.cuda(), ndc=ndc, patch=patch, retraw=True, **nf, **extra, **kw)
+            ref = O.render(H, W, f, c2w=c2w, ndc=ndc, patch=patch, retraw=True, **nf, **oextra, **okw)
+        assert tuple(got[0].shape) == tuple(ref[0].shape)
+        _cmp_maps(got, ref)
+
+
+def test_render_with_depths_column_and_per_ray_bounds(S):
+    """render(rays=..., depths=...) (run_nerf.py:148-149, the COLMAP-depth render of train(), :1473-1477) and near / far
+    given per ray (:106-107): the packed row carries the depth column in front of the viewdirs."""
+    O, kw, okw = _coarse_setup(S)
+    H, W, f = 10, 12, 14.0
+    rs = np.random.RandomState(2)
+    n = 50
+    ro = torch.from_numpy(rs.normal(scale=0.2, size=(n, 3)).astype(np.float32))
+    rd = torch.from_numpy((rs.normal(size=(n, 3)) * [0.3, 0.3, 0.1] + [0, 0, -1]).astype(np.float32))
+    depths = torch.from_numpy(rs.uniform(2, 4, size=n).astype(np.float32))
+    near = torch.from_numpy(rs.uniform(1.0, 1.5, size=(n, 1)).astype(np.float32))
+    far = near + torch.from_numpy(rs.uniform(2.0, 4.0, size=(n, 1)).astype(np.float32))
+    rows = S.ops.pack_rays(ro.cuda(), rd.cuda(), H, W, f, ndc=False, near=near.cuda(), far=far.cuda(), use_viewdirs=True,
+                           depths=depths.cuda()).cpu()
+    vdirs = rd / torch.norm(rd, dim=-1, keepdim=True)
+    close(rows, torch.cat([ro, rd, near, far, depths[:, None], vdirs], -1), atol=1e-6, rtol=2e-6)
+    with torch.no_grad():
+        got = S.render(H, W, f, rays=torch.stack([ro, rd], 0).cuda(), ndc=False, near=near.cuda(), far=far.cuda(),
+                       depths=depths.cuda(), retraw=True, **kw)
+        ref = O.render(H, W, f, rays=torch.stack([ro, rd], 0), ndc=False, near=near, far=far, depths=depths,
+                       retraw=True, **okw)
+    _cmp_maps(got, ref)
+
+
+def test_embedder_call_matches_reference_embedding(S):
+    """get_embedder()[0](x) (helpers:22-70) — the standalone encoding kernel; the identity embedder passes through"""
+    from oracle import nerf_oracle as O
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.uniform(-3, 3, size=(7, 5, 3)).astype(np.float32))
+    for L in (10, 4, 0):
+        e, d = S.get_embedder(L, 0)
+        out = e(x.cuda())
+        assert tuple(out.shape) == (7, 5, d)
+
+        close(out, O.embed(x.reshape(-1, 3), L, 0).reshape(7, 5, d), atol=2e-6, rtol=0)
+    e, d = S.get_embedder(10, -1)
+    assert d == 3 and torch.equal(e(x), x)

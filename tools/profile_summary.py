@@ -29,6 +29,7 @@ if stats:
             break
         print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
               f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
+pmc_json = {}
 for kind, title in (("pmc_sq", "SQ counters (avg per launch)"), ("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = find(f"{tag}_{kind}/**/*counter_collection.csv")
     if not f:
@@ -36,11 +37,22 @@ for kind, title in (("pmc_sq", "SQ counters (avg per launch)"), ("pmc_fetch", "F
     acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
-        if "mlp_" in k:
+        if "snr::" in r["Kernel_Name"]:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f"\n## {title}\n")
     for k in sorted(acc):
         vals = ", ".join(f"{c}={sum(v) / len(v):.4g}" for c, v in sorted(acc[k].items()))
         print(f"- `{k}` (n={len(next(iter(acc[k].values())))}): {vals}")
+        if kind != "pmc_sq":
+            for c, v in acc[k].items():
+                pmc_json.setdefault(k.split("<")[0], {})[c + "_KiB_per_launch"] = sum(v) / len(v)
 print("\nFETCH_SIZE / WRITE_SIZE are in KiB per launch as reported; per MI355X_MICROARCH.md the read side of a wide "
       "coalesced stream is under-reported 2x on gfx950 (double FETCH_SIZE before comparing with byte counts).")
+
+# machine-readable copy for bench.py's roofline.traffic / hbm_bytes_per_step (per-kernel averages over all launches of
+# the default bench command; launches per step come from bench.py itself)
+import json
+if pmc_json:
+    with open(os.path.join(out, f"{tag}_pmc.json"), "w") as fh:
+        json.dump({"command": "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-frame",
+                   "workload": "bf16, N_rand=1024, 64c+128f", "kernels": pmc_json}, fh, indent=1)
