@@ -468,11 +468,15 @@ __global__ __launch_bounds__(256) void wgrad_post_kernel(PostArgs a) {
   const float* Wf = a.params + a.w_feat;
   const int t = blockIdx.x;
   if (t == 96) {
-    const int j = tid;   // 256 threads
-    float s = 0.f;
-    for (int m = 0; m < kW / 2; ++m) s += wround<P>(Wv[(int64_t)m * a.ld_views + j]) * s9[m];
+    const int j = tid;   // 256 threads; independent partial sums so that the 128 loads are in flight together
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m0 = 0; m0 < kW / 2; m0 += 8)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += wround<P>(Wv[(int64_t)(m0 + u) * a.ld_views + j]) * s9[m0 + u];
+    const float tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     float* d = a.grad + a.b_feat + j;
-    *d = a.accumulate ? *d + s : s;
+    *d = a.accumulate ? *d + tot : tot;
     return;
   }
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(256) void wgrad_post_kernel(PostArgs a) {
     // C[j][k] = sum_m A[j][m] B[m][k], A[j][m] = Wv[m][j0 + j], B[m][k] = G[m][k0 + k]; m = 32 * wave + 2 * s + h
     r0 = 32 * (t >> 3); c0 = 32 * (t & 7);
     const int m0 = 32 * wave;
-#pragma unroll 8
+#pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int m = m0 + 2 * s + h;
       const float av = wround<P>(Wv[(int64_t)m * a.ld_views + r0 + i]);
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(256) void wgrad_post_kernel(PostArgs a) {
     const int k0 = 64 * wave;
     const float* ga = G + (int64_t)(r0 + i) * kW + k0 + 4 * h;
     const float* wb = Wf + (int64_t)(c0 + i) * kW + k0 + 4 * h;
-#pragma unroll 4
+#pragma unroll
     for (int s = 0; s < 8; ++s) {
       const f32x4 av = *(const f32x4*)(ga + 8 * s);
       const f32x4 bv = *(const f32x4*)(wb + 8 * s);

@@ -41,7 +41,9 @@ def close(a, b, atol=1e-6, rtol=1e-5, msg=""):
 
 
 def mostly_close(a, b, atol, rtol, frac, hard_atol, msg=""):
-    """at least `frac` of the elements within (atol, rtol); every element within hard_atol (NaNs must coincide)."""
+    """at least `frac` of the elements within (atol, rtol); every element within hard_atol — None: finite wherever the
+    reference is, the per-ray bound being test_free_running_errors_are_attributed_to_displaced_samples' job —
+    (NaNs must coincide)."""
     a, b = npy(a), npy(b)
     assert a.shape == b.shape, msg
     nan = np.isnan(b)
@@ -49,7 +51,10 @@ def mostly_close(a, b, atol, rtol, frac, hard_atol, msg=""):
     d = np.abs(a - b)[~nan]
     ok = d <= atol + rtol * np.abs(b[~nan])
     assert ok.mean() >= frac, f"{msg}: only {ok.mean() * 100:.2f}% within tolerance"
-    assert d.max(initial=0.0) <= hard_atol, f"{msg}: max |diff| {d.max():.3e}"
+    if hard_atol is None:
+        assert np.isfinite(a[np.isfinite(b)]).all(), msg
+    else:
+        assert d.max(initial=0.0) <= hard_atol, f"{msg}: max |diff| {d.max():.3e}"
 
 
 def build(S, g, precision="fp32"):
@@ -112,19 +117,106 @@ def test_render_forward_matches_reference(S, name, hook):
         close(extras["acc0"], g["x_acc0"], atol=2e-4, msg="acc0")
         close(extras["disp0"], g["x_disp0"], rtol=1e-3, atol=1e-4, msg="disp0")
         # free-running fine stage: see module docstring
-        mostly_close(extras["z_vals"], g["x_z_vals"], 1e-4, 1e-5, 0.96, 1e9, "z_vals")
+        mostly_close(extras["z_vals"], g["x_z_vals"], 1e-4, 1e-5, 0.96, None, "z_vals")
         mostly_close(extras["weights"], g["x_weights"], 2e-4, 0, 0.98, 0.5, "weights")
         mostly_close(rgb, g["rgb"], 2e-4, 0, 0.90, 1e-2, "rgb")
         mostly_close(acc, g["acc"], 2e-4, 0, 0.98, 1e-2, "acc")
         mostly_close(depth, g["depth"], 2e-4, 1e-3, 0.90, 5e-2, "depth")
-        mostly_close(disp, g["disp"], 2e-4, 1e-3, 0.85, 1e9, "disp")
-        mostly_close(extras["z_std"], g["x_z_std"], 2e-4, 1e-3, 0.80, 1e9, "z_std")
+        mostly_close(disp, g["disp"], 2e-4, 1e-3, 0.85, None, "disp")
+        mostly_close(extras["z_std"], g["x_z_std"], 2e-4, 1e-3, 0.80, None, "z_std")
     else:
         close(rgb, g["rgb"], atol=2e-5); close(acc, g["acc"], atol=2e-5)
         close(depth, g["depth"], rtol=1e-4, atol=2e-5); close(disp, g["disp"], rtol=1e-4, atol=2e-5)
         close(extras["z_vals"], g["x_z_vals"], atol=1e-6)
         close(extras["weights"], g["x_weights"], atol=2e-5)
         close(extras["raw"], g["x_raw"], atol=2e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name", [n for n in RENDER_CASES if int(load(n)["Nf"]) > 0])
+def test_free_running_errors_are_attributed_to_displaced_samples(S, name):
+    """The free-running fine stage cannot be held element-wise (module docstring; the reference's own fp32 vs fp64 flip
+    rate is pinned in tests/test_oracle_golden.py).  What CAN be held, per ray, with dz = the largest displacement among
+    the ray's 192 z_vals:
+      * rays whose z_vals agree to the last bits (dz <= 2e-6 relative; 40-90 % of the rays) meet tight gates:
+        rgb / acc / depth 5e-5, disparity 1e-4 relative, z_std 1e-5 (measured 1.2e-5 / 1.5e-5 / 1.1e-5 / 1.5e-5 / 3e-6);
+      * every other ray's error is bounded by the tight gate plus a Lipschitz constant times its OWN dz (measured slopes:
+        rgb 3.2, acc 0.08, depth 1.1, relative disparity 6.9, z_std 0.24; gates 3x that): an outlier is explained by a
+        displaced sample, never by anything else."""
+    g = load(name)
+    net_c, net_f, kw = build(S, g)
+    with torch.no_grad():
+        rgb, disp, acc, depth, ex = run(S, g, kw, True)
+    n = g["rgb"].reshape(-1, 3).shape[0]
+    zr = g["x_z_vals"].reshape(n, -1)
+    dz = np.abs(npy(ex["z_vals"]).reshape(n, -1) - zr).max(-1)
+    tight = dz <= 2e-6 * np.maximum(1.0, np.abs(zr).max(-1))
+    assert tight.mean() >= 0.25, f"only {tight.mean() * 100:.1f}% of the rays reproduce the reference's z_vals to the last bits"
+    ref_disp = g["disp"].reshape(n)
+    errs = {
+        "rgb": (np.abs(npy(rgb).reshape(n, 3) - g["rgb"].reshape(n, 3)).max(-1), 5e-5, 10.0),
+        "acc": (np.abs(npy(acc).reshape(n) - g["acc"].reshape(n)), 5e-5, 1.0),
+        "depth": (np.abs(npy(depth).reshape(n) - g["depth"].reshape(n)), 5e-5, 4.0),
+        "disp": (np.abs(npy(disp).reshape(n) - ref_disp) / np.maximum(np.abs(ref_disp), 1e-12), 1e-4, 25.0),
+        "z_std": (np.abs(npy(ex["z_std"]).reshape(n) - g["x_z_std"].reshape(n)), 1e-5, 1.0),
+    }
+    occupied = np.abs(g["acc"].reshape(n)) > 1e-3   # disparity = 1 / (depth / acc) is a 0 / 0 quotient on empty rays
+    for k, (e, gate, lip) in errs.items():
+        ok = np.isfinite(e)          # NaN disparities (0 / 0) coincide with the reference's: checked by mostly_close
+        if k == "disp":
+            ok &= occupied
+        bound = gate + lip * dz
+        worst = np.argmax(np.where(ok, e - bound, -np.inf))
+        assert (e[ok] <= bound[ok]).all(), (f"{k}: ray {worst} is off by {e[worst]:.3e} with its samples displaced by "
+                                            f"{dz[worst]:.3e} at most")
+
+
+# bf16 gates (stated; calibrated on MI355X with tests/probes/render_diag.py, about 2x the measured maxima).  The render
+# fixtures use networks whose raw outputs reach +-12...20 and swing with 2^9-frequency encodings; bf16 keeps 8 bits per
+# activation through 10 layers, so raw is off by up to 1.3 % of its range (measured 0.11-0.25) and the 64-sample coarse
+# composite by up to 0.03.  On default-initialised networks the same path is 10x tighter (tests/test_gpu_kernels.py).
+BF16 = dict(raw_frac=0.025, coarse_rgb=6e-2, coarse_acc=6e-2, rgb=1e-2, acc=1e-2, weights=1e-2, depth_atol=1e-2,
+            depth_rtol=2e-2, disp_rtol=2.5e-2)
+
+
+@pytest.mark.parametrize("name", RENDER_CASES)
+def test_render_bf16_coarse_stage_and_teacher_forced_fine_stage(S, name):
+    """The benched dtype at render() level, against the reference fixtures ("bf16 mode: state separately"):
+    the coarse stage of render() and the fine stage teacher-forced on the reference's z_vals, gates in BF16 above."""
+    g = load(name)
+    net_c, net_f, kw = build(S, g, "bf16")
+    with torch.no_grad():
+        rgb, disp, acc, depth, ex = run(S, g, kw, True)
+    n = g["rgb"].reshape(-1, 3).shape[0]
+    if int(g["Nf"]) == 0:
+        close(rgb, g["rgb"], atol=BF16["coarse_rgb"], rtol=0, msg="rgb"); close(acc, g["acc"], atol=BF16["coarse_acc"], rtol=0, msg="acc")
+        scale = float(np.abs(g["x_raw"]).max())
+        close(ex["raw"], g["x_raw"], atol=BF16["raw_frac"] * scale, rtol=0, msg="raw")
+        close(ex["weights"], g["x_weights"], atol=BF16["coarse_rgb"], rtol=0, msg="weights")
+        assert set(ex.keys()) == {k[2:] for k in g if k.startswith("x_")}
+        return
+    close(ex["rgb0"], g["x_rgb0"], atol=BF16["coarse_rgb"], rtol=0, msg="rgb0")
+    close(ex["acc0"], g["x_acc0"], atol=BF16["coarse_acc"], rtol=0, msg="acc0")
+    assert set(ex.keys()) == {k[2:] for k in g if k.startswith("x_")}
+    rays = pack_rays(S, g)
+    z = T(g["x_z_vals"]).reshape(n, -1).cuda()
+    vd = bool(g["vd"])
+    with torch.no_grad():
+        raw = net_f.query_rays(rays, z, rays[:, -3:] if vd else None)
+    ref_raw = g["x_raw"].reshape(n, z.shape[1], -1)
+    close(raw, ref_raw, atol=BF16["raw_frac"] * float(np.abs(ref_raw).max()), rtol=0, msg="raw")
+    noise = None
+    if float(g["noise_std"]) > 0:
+        rnd = chunked_pytest_randoms(n, int(g["chunk"]), 64, int(g["Nf"]), float(g["perturb"]), float(g["noise_std"]))
+        noise = rnd["noise_f"].cuda()
+    with torch.no_grad():   # composite the kernel's OWN bf16 raw: the whole fine stage, z_vals excepted
+        r2, d2, a2, w2, dp2, _ = S.raw2outputs(raw, z, rays[:, 3:6], white_bkgd=bool(g["white"]), noise=noise, rays=rays)
+    close(r2, g["rgb"].reshape(n, 3), atol=BF16["rgb"], rtol=0, msg="rgb")
+    close(a2, g["acc"].reshape(n), atol=BF16["acc"], rtol=0, msg="acc")
+    close(w2, g["x_weights"].reshape(n, -1), atol=BF16["weights"], rtol=0, msg="weights")
+    close(dp2, g["depth"].reshape(n), atol=BF16["depth_atol"], rtol=BF16["depth_rtol"], msg="depth")
+    ref_d, got_d = g["disp"].reshape(n), npy(d2)
+    ok = np.isfinite(ref_d) & (np.abs(g["acc"].reshape(n)) > 0.05)   # disparity = acc / depth is ill-conditioned on empty rays
+    close(got_d[ok], ref_d[ok], atol=1e-6, rtol=BF16["disp_rtol"], msg="disp")
 
 
 def pack_rays(S, g):
@@ -183,7 +275,7 @@ def test_render_unfused_query_path_equals_fused(S):
     with torch.no_grad():
         a = run(S, g, kw, True, fused=True)
         b = run(S, g, kw, True, fused=False)
-    mostly_close(a[4]["z_vals"], b[4]["z_vals"], 1e-6, 0, 0.98, 1e9, "z_vals")
+    mostly_close(a[4]["z_vals"], b[4]["z_vals"], 1e-6, 0, 0.98, None, "z_vals")
     mostly_close(a[0], b[0], 1e-5, 0, 0.95, 1e-2, "rgb")
     close(a[4]["rgb0"], b[4]["rgb0"], atol=1e-5)
 
