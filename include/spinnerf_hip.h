@@ -86,6 +86,32 @@ int snr_mlp_backward(const snr_mlp_config* cfg, const void* packed, const float*
                      int64_t n_samples, const void* act, void* ws, float* grad_params, int accumulate,
                      snr_stream_t stream);
 
+/* ---- hash-grid radiance network: replaces NeRF_TCNN.forward and its autograd (run_nerf_helpers_tcnn.py:13-113; the
+ * reference's default network, create_nerf_tcnn, run_nerf.py:499-590).  The reference delegates this arithmetic to
+ * tiny-cuda-nn (tcnn.Encoding "HashGrid" / "SphericalHarmonics", tcnn.Network "FullyFusedMLP"): parity unpinned, the
+ * definition followed is restated in oracle/hashgrid_oracle.py.  All configuration values are the reference's constants
+ * (16 levels x 2 features, 2^19 entries, base 16, bound 100, SH degree 4, 32->64->16 and 32->64->64->16 bias-free MLPs).
+ * `params` = one flat fp32 buffer [table entries x 2 | sigma_net.params | color_net.params] (state-dict order). */
+int64_t snr_hashgrid_table_entries(void);
+int64_t snr_hashgrid_param_count(void);
+int64_t snr_hashgrid_packed_bytes(void);
+int64_t snr_hashgrid_act_bytes(int64_t n_samples);
+int64_t snr_hashgrid_bwd_ws_bytes(int64_t n_samples);
+/* MLP weights -> MFMA fragment order (call after every optimizer step; the table is read in place) */
+int snr_hashgrid_pack(const float* params, void* packed, snr_stream_t stream);
+/* raw[n_samples,4] = (colour 3 — no activation, sigma) for sample positions `pts` [n,3] or o + d*z formed in-kernel from
+ * `rays` / `z_vals` (as snr_mlp_forward); `viewdirs` (unit, per ray) is required: the network reads input[:, 3:]
+ * (tcnn.py:88).  `act` NULL = inference, else snr_hashgrid_act_bytes() that backward consumes. */
+int snr_hashgrid_forward(const float* params, const void* packed, const float* pts, const float* rays, int ray_ld,
+                         const float* z_vals, const float* viewdirs, int viewdirs_ld, int64_t n_samples,
+                         int samples_per_ray, float* raw, void* act, snr_stream_t stream);
+/* d(loss)/d(params) from d(loss)/d(raw) [n,4] for the same inputs as the forward call.  grad_params (flat, fp32):
+ * overwritten if accumulate == 0 (the table part is cleared, then accumulated with atomics), else += . */
+int snr_hashgrid_backward(const float* params, const void* packed, const float* pts, const float* rays, int ray_ld,
+                          const float* z_vals, const float* viewdirs, int viewdirs_ld, const float* d_raw,
+                          int64_t n_samples, int samples_per_ray, const void* act, void* ws, float* grad_params,
+                          int accumulate, snr_stream_t stream);
+
 /* ---- stratified sampling: replaces run_nerf.py:646-668 ----
  * z_vals[n_rays, n_samples] from near/far = rays[:,6], rays[:,7]; lindisp per run_nerf.py:647-650;
  * t_rand [n_rays, n_samples] non-NULL = perturb (run_nerf.py:654-668). */

@@ -42,6 +42,14 @@ SIGNATURES = {
     "snr_mlp_pack": (_i, [_CFG, _p, _p, _p]),
     "snr_mlp_forward": (_i, [_CFG, _p, _p, _p, _i, _p, _p, _i, _l, _i, _p, _p, _p]),
     "snr_mlp_backward": (_i, [_CFG, _p, _p, _p, _l, _p, _p, _p, _i, _p]),
+    "snr_hashgrid_table_entries": (_l, []),
+    "snr_hashgrid_param_count": (_l, []),
+    "snr_hashgrid_packed_bytes": (_l, []),
+    "snr_hashgrid_act_bytes": (_l, [_l]),
+    "snr_hashgrid_bwd_ws_bytes": (_l, [_l]),
+    "snr_hashgrid_pack": (_i, [_p, _p, _p]),
+    "snr_hashgrid_forward": (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _l, _i, _p, _p, _p]),
+    "snr_hashgrid_backward": (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _p, _l, _i, _p, _p, _p, _i, _p]),
     "snr_sample_coarse": (_i, [_p, _i, _l, _i, _i, _p, _p, _p]),
     "snr_composite_forward": (_i, [_p, _i, _p, _p, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "snr_composite_backward": (_i, [_p, _i, _p, _p, _i, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -22,6 +22,7 @@ SOURCES = [
     ("mlp_fwd.hip", ["-save-temps=obj"]),
     ("mlp_bwd.hip", ["-save-temps=obj"]),
     ("render_ops.hip", ["-ffp-contract=off"]),
+    ("hashgrid.hip", ["-munsafe-fp-atomics"]),   # table gradients: hardware global_atomic_add_f32, no CAS loops
     ("prof.cpp", ["-x", "hip"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]

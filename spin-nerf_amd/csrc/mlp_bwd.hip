@@ -198,6 +198,23 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
 
 }  // namespace snr
 
+int snr::wgrad_launch_bf16(const WgradArgs& w, int total_splits, float* grad, int accumulate, hipStream_t s) {
+  constexpr int lds = WgradCfg<kBF16>::RING * 2 * Blob<kBF16>::KS_H * 1024;
+  if (int e = ensure_dynamic_lds<&mlp_wgrad_kernel<kBF16>>(lds)) return e;
+  {
+    ProfScope ps(K_MLP_WGRAD, s);
+    mlp_wgrad_kernel<kBF16><<<dim3((unsigned)total_splits), dim3(64 * kWgradWaves), lds, s>>>(w);
+  }
+  int st = launch_status();
+  if (st != SNR_OK) return st;
+  const int per_out = 256 * (256 / 4 + 1);
+  {
+    ProfScope ps(K_MLP_WGRAD_REDUCE, s);
+    mlp_wgrad_reduce_kernel<kBF16><<<dim3((per_out + 255) / 256, (unsigned)w.n_outs), dim3(256), 0, s>>>(w, grad, accumulate);
+  }
+  return launch_status();
+}
+
 using namespace snr;
 
 static int check_cfg_b(const snr_mlp_config* c) {
@@ -280,7 +297,7 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
       pa.params = params; pa.post = w.post; pa.grad = grad;
       pa.w_views = (int)L.w_views; pa.ld_views = kW + L.in_dir; pa.w_feat = (int)L.w_feat; pa.b_feat = (int)L.b_feat;
       pa.accumulate = accumulate;
-      wgrad_post_kernel<P><<<dim3(97), dim3(256), 0, s>>>(pa);
+      wgrad_post_kernel<P><<<dim3(104), dim3(256), 0, s>>>(pa);
     }
   }
   return launch_status();

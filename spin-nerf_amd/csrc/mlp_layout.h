@@ -102,6 +102,14 @@ template <int P> SNR_HD int enc_slot_feature(int q, int g, int e, int L) {
   return -1;
 }
 
+// Hash-grid colour network (hashgrid.hip): its second input k-step is the sigma network's 16-row output tile as it sits
+// in registers — slot (g, e) holds row (e&3) + 8(e>>2) + 4g; row 0 (sigma) is replaced by the constant-1 padding input
+// (column 31 of the 32-wide first layer), row j by geo feature j-1 (column 15 + j).
+SNR_HD int hg_inc_col(int g, int e) {
+  const int row = (e & 3) + 8 * (e >> 2) + 4 * g;
+  return row == 0 ? 31 : 15 + row;
+}
+
 // ---- flat parameter buffer (state-dict order of the reference module) -------------------------
 // pts_linears.{0..7}.{weight,bias}, views_linears.0.{weight,bias}, then with viewdirs
 // feature_linear, alpha_linear, rgb_linear; without: output_linear.  (helpers:86-102)

@@ -5,7 +5,9 @@
 
 namespace snr {
 
-enum SrcKind { SRC_NONE = 0, SRC_ENC_PTS = 1, SRC_ENC_DIR = 2, SRC_H = 3, SRC_OUT = 4 };
+enum SrcKind { SRC_NONE = 0, SRC_ENC_PTS = 1, SRC_ENC_DIR = 2, SRC_H = 3, SRC_OUT = 4,
+               SRC_NAT = 5,       // slot x = column x (hash-grid features)
+               SRC_HG_INC = 6 };  // hash-grid colour-network input: 16 SH slots, then mlp_layout.h: hg_inc_col
 
 // One source segment of a stage's contraction: `ks` frags whose k-slots map to weight columns
 // (forward) or weight rows (transposed / dgrad).

@@ -373,10 +373,15 @@ __global__ __launch_bounds__(64 * kWgradWaves) void mlp_wgrad_kernel(WgradArgs a
     if (nx == 0) SNR_RUN(1, 0, 3, 5);
     else if (ntb == 8) SNR_RUN(8, 1, 3, 5);
     else SNR_RUN(2, 1, 3, 5);
-  } else {
+  } else if (ni == 2) {
     if (nx == 0) SNR_RUN(1, 0, 2, 5);
     else if (ntb == 4) SNR_RUN(4, 1, 2, 5);
     else SNR_RUN(1, 1, 2, 5);
+  } else {   // one DMA instruction per wave per tile: the small hash-grid jobs (1x1, 2x1, 1x2, 2x2 tiles of 5..8 KiB).
+             // NI must equal the instructions really issued — the counted wait's immediate is NI * (tiles in flight)
+    if (nx == 0) SNR_RUN(1, 0, 1, 5);
+    else if (ntb == 2) SNR_RUN(2, 1, 1, 5);
+    else SNR_RUN(1, 1, 1, 5);
   }
 #undef SNR_RUN
 }
@@ -389,6 +394,8 @@ template <int P> __device__ __forceinline__ int slot_true_index(int kind, int x,
   const int q = x / (2 * EPF), g = (x % (2 * EPF)) / EPF, e = x % EPF;
   if (kind == SRC_H) return h_slot_neuron<P>(q, g, e);
   if (kind == SRC_ENC_PTS || kind == SRC_ENC_DIR) return enc_slot_feature<P>(q, g, e, L);
+  if (kind == SRC_NAT) return x;
+  if (kind == SRC_HG_INC) return q == 0 ? 8 * g + e : hg_inc_col(g, e);   // (bf16 only)
   return (P == kBF16) ? 8 * g + e : 2 * e + g;  // SRC_OUT (single frag): raw channel
 }
 
@@ -439,9 +446,9 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, i
 // ------------------------------------------------------------------------------------------
 // the two dense products behind G (header comment): exact fp32 MFMA, one workgroup of 4 waves per 32 x 32 output
 // tile, each wave a quarter of the contraction, summed through LDS.
-//   tiles  0..63 : dW_feat[j][k]        = sum_m Wv[m][j] G[m][k]                  (256 x 256, contraction 128)
-//   tiles 64..95 : dW_views[m][j < 256] = sum_k G[m][k] Wf[j][k] + s9[m] b_f[j]   (128 x 256, contraction 256)
-//   tile  96     : db_feat[j]           = sum_m Wv[m][j] s9[m]
+//   tiles  0..71  : dW_feat[j][k]        = sum_m Wv[m][j] G[m][k]                  (256 x 256, contraction 128), with s9
+//                   as a 257th column of G: db_feat[j] = sum_m Wv[m][j] s9[m]
+//   tiles 72..103 : dW_views[m][j < 256] = sum_k G[m][k] Wf[j][k] + s9[m] b_f[j]   (128 x 256, contraction 256)
 // P == bf16 rounds the two weight matrices to bf16 first: the forward and dgrad kernels evaluated the layers with the
 // rounded weights, and the products restate exactly those layers.
 // ------------------------------------------------------------------------------------------
@@ -467,36 +474,25 @@ __global__ __launch_bounds__(256) void wgrad_post_kernel(PostArgs a) {
   const float* Wv = a.params + a.w_views;
   const float* Wf = a.params + a.w_feat;
   const int t = blockIdx.x;
-  if (t == 96) {
-    const int j = tid;   // 256 threads; independent partial sums so that the 128 loads are in flight together
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int m0 = 0; m0 < kW / 2; m0 += 8)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s[u] += wround<P>(Wv[(int64_t)(m0 + u) * a.ld_views + j]) * s9[m0 + u];
-    const float tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-    float* d = a.grad + a.b_feat + j;
-    *d = a.accumulate ? *d + tot : tot;
-    return;
-  }
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int r0, c0;   // output tile origin
-  if (t < 64) {
-    // C[j][k] = sum_m A[j][m] B[m][k], A[j][m] = Wv[m][j0 + j], B[m][k] = G[m][k0 + k]; m = 32 * wave + 2 * s + h
-    r0 = 32 * (t >> 3); c0 = 32 * (t & 7);
+  if (t < 72) {
+    // C[j][k] = sum_m A[j][m] B[m][k], A[j][m] = Wv[m][j0 + j], B[m][k] = G[m][k0 + k]; m = 32 * wave + 2 * s + h.
+    // G is extended by one column tile whose first column is s9: C[j][256] = db_feat[j].
+    r0 = 32 * (t / 9); c0 = 32 * (t % 9);
     const int m0 = 32 * wave;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int m = m0 + 2 * s + h;
       const float av = wround<P>(Wv[(int64_t)m * a.ld_views + r0 + i]);
-      const float bv = G[m * kW + c0 + i];
+      const float bv = c0 < kW ? G[m * kW + c0 + i] : (i == 0 ? s9[m] : 0.f);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
   } else {
     // C[m][j] = sum_k A[m][k] B[k][j], A[m][k] = G[m0 + m][k], B[k][j] = Wf[j0 + j][k]; both contiguous in k:
     // a lane loads 4 consecutive k (16 B) and spends them on 4 MFMA steps — step e of a group uses k = base + 4 h + e
     // on both operands
-    const int tt = t - 64;
+    const int tt = t - 72;
     r0 = 32 * (tt >> 3); c0 = 32 * (tt & 7);
     const int k0 = 64 * wave;
     const float* ga = G + (int64_t)(r0 + i) * kW + k0 + 4 * h;
@@ -521,8 +517,13 @@ __global__ __launch_bounds__(256) void wgrad_post_kernel(PostArgs a) {
       const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * h, col = c0 + i;
       float* d;
       float val = v;
-      if (t < 64) {
-        d = a.grad + a.w_feat + (int64_t)row * kW + col;
+      if (t < 72) {
+        if (col >= kW) {
+          if (col > kW) continue;
+          d = a.grad + a.b_feat + row;
+        } else {
+          d = a.grad + a.w_feat + (int64_t)row * kW + col;
+        }
       } else {
         val += s9[row] * a.params[a.b_feat + col];
         d = a.grad + a.w_views + (int64_t)row * a.ld_views + col;
@@ -531,6 +532,9 @@ __global__ __launch_bounds__(256) void wgrad_post_kernel(PostArgs a) {
     }
   }
 }
+
+// split-K kernel + reduce of a prepared bf16 job list (defined in mlp_bwd.hip; also serves hashgrid.hip)
+int wgrad_launch_bf16(const WgradArgs& w, int total_splits, float* grad, int accumulate, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
 // host: job list
