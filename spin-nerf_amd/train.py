@@ -98,7 +98,7 @@ class RenderTrainer:
         return loss, rgb.detach()
 
     def spin_loss(self, H, W, focal, batch_rays_clf, target_clf, batch_rays, target_s, batch_inp=None,
-                  depth_inp=None, chunk=1024 * 32, randoms=None, batched=False, **extra):
+                  depth_inp=None, chunk=1024 * 32, randoms=None, batched=False, colmap_depth=None, lpips=None, **extra):
         """Loss of one SPIn-NeRF iteration in its default mode (run_nerf.py:1455-1521, no --masked_NeRF /
         --object_removal / --prepare / --no_geometry, LPIPS and COLMAP-depth terms excluded — SURVEY.md §8 f-1):
 
@@ -107,10 +107,23 @@ class RenderTrainer:
           render(rays with an inpainted-disparity target)     -> MSE(disp, depth_inp) + MSE(disp0, depth_inp),
                                                                  skipped when NaN like the reference (:1518-1521)
 
-        ``randoms`` = optional list of three injected-random dicts (one per render, as for render()) so that
+        Optional terms of the same iteration:
+          colmap_depth = dict(rays=[2,N,3], target=[N] depths, weights=[N] or None, depth_lambda=..., mode='mse' |
+                         'weighted' | 'weighted_normalized' | 'relative', max_depth=...)
+              -> render(rays, depths=target) and depth_lambda * the depth loss of run_nerf.py:1473-1507 (--colmap_depth
+                 --depth_loss with --weighted_loss / --normalize_depth / --relative_loss); its randoms = randoms[3]
+          lpips        = dict(fn=<perceptual distance on [-1,1] NCHW batches>, poses=[B,3,4], images=[B,H,W,3],
+                         masks=[B,H,W], hwf=(H,W,focal), render_kwargs=<test kwargs>, render_factor=1, patch_len_factor=4)
+              -> the patch renders with gradients of run_nerf.py:1523-1561 (render_path in patch mode, detach_weights=True)
+                 and sum(fn(prediction, target patch)) / B / 100.  The LPIPS network itself is not part of this package
+                 (its VGG weights are a download); any callable with that contract plugs in.
+
+        ``randoms`` = optional list of injected-random dicts (one per render, as for render()) so that
         parity tests can pin the draws.  ``batched`` runs the first and the third render as one.
-        Returns (loss, dict of the three render outputs)."""
-        rnd = randoms or [None, None, None]
+        Returns (loss, dict of the render outputs)."""
+        rnd = list(randoms or [None, None, None])
+        while len(rnd) < 4:
+            rnd.append(None)
         kw = dict(chunk=chunk, retraw=True, **extra, **self.kw)
         ex_i = disp_i = None
         if batched and batch_inp is not None:
@@ -143,7 +156,63 @@ class RenderTrainer:
             if not bool(torch.isnan(inp)):
                 loss = loss + inp
             outs["inp"] = (disp_i, ex_i)
+        if colmap_depth is not None:                               # run_nerf.py:1473-1477, 1492-1507
+            cd = colmap_depth
+            tgt = cd["target"]
+            _, _, _, depth_col, ex_col = render(H, W, focal, rays=cd["rays"], depths=tgt, randoms=rnd[3], **kw)
+            mode = cd.get("mode", "mse")
+            if mode == "weighted":
+                d_loss = torch.mean(((depth_col - tgt) ** 2) * cd["weights"])
+            elif mode == "weighted_normalized":
+                d_loss = torch.mean((((depth_col - tgt) / cd["max_depth"]) ** 2) * cd["weights"])
+            elif mode == "relative":
+                d_loss = torch.mean(((depth_col - tgt) / tgt) ** 2)
+            else:
+                d_loss = img2mse(depth_col, tgt)
+            loss = loss + cd.get("depth_lambda", 0.1) * d_loss
+            outs["colmap"] = (depth_col, ex_col)
+        if lpips is not None:                                      # run_nerf.py:1523-1561
+            loss = loss + self.lpips_term(chunk=chunk, **lpips)
         return loss, outs
+
+    def lpips_term(self, fn, poses, images, masks, hwf, render_kwargs, render_factor=1, patch_len_factor=4,
+                   chunk=1024 * 32):
+        """Patch renders WITH gradients of `poses` (render_path's patch mode: corner drawn inside each mask's bounding
+        box, detach_weights=True) against the same patch of the (resized) training images, mapped to [-1, 1] NCHW like
+        the reference feeds its LPIPS network; returns sum(fn(pred, target).mean()) / B / 100 (run_nerf.py:1523-1561)."""
+        from .path import render_path
+        import torch.nn.functional as F
+        Hh, Ww = int(hwf[0]) // render_factor, int(hwf[1]) // render_factor
+        patch_len = (Hh // patch_len_factor, Ww // patch_len_factor)
+        rgbs, _, (Xs, Ys) = render_path(poses, hwf, chunk, render_kwargs, render_factor=render_factor,
+                                        rgb_require_grad=True, need_alpha=False, detach_weights=True,
+                                        patch_len=patch_len, masks=masks)
+        total = 0.
+        for b in range(len(poses)):
+            pred = ((rgbs[b] - 0.5) * 2).permute(2, 0, 1)[None, ...]
+            tgt = ((images[b] - 0.5) * 2).permute(2, 0, 1)[None, ...]
+            if tuple(tgt.shape[-2:]) != (Hh, Ww):     # torchvision.transforms.Resize (bilinear, antialiased) in the reference
+                tgt = F.interpolate(tgt, size=(Hh, Ww), mode="bilinear", antialias=True, align_corners=False)
+            tgt = tgt[:, :, Xs[b]:Xs[b] + patch_len[0], Ys[b]:Ys[b] + patch_len[1]]
+            total = total + fn(pred, tgt.to(pred.device)).mean()
+        return total / len(poses) / 100
+
+    def export_disparities(self, poses, hwf, render_kwargs, masks, out_dir, render_factor=1, chunk=1024 * 32):
+        """--prepare (run_nerf.py:1563-1609): render every training pose without gradients and write the disparity maps
+        (x 255, 8-bit PNG) and the masks subsampled by render_factor (x 255) as the depth-inpainting input:
+        <out_dir>/img{i:03}.png and <out_dir>/label/img{i:03}.png."""
+        import os
+        import numpy as np
+        from .path import render_path, write_png
+        os.makedirs(os.path.join(out_dir, "label"), exist_ok=True)
+        with torch.no_grad():
+            _, disps, _ = render_path(poses, hwf, chunk, render_kwargs, render_factor=render_factor)
+        for i in range(len(poses)):
+            d = np.nan_to_num(np.asarray(disps[i], dtype=np.float64) * 255, nan=0.0)   # cv2.imwrite casts with saturation
+            write_png(os.path.join(out_dir, f"img{i:03d}.png"), np.clip(np.rint(d), 0, 255).astype(np.uint8))
+            m = np.asarray(masks[i])[::render_factor, ::render_factor] * 255
+            write_png(os.path.join(out_dir, "label", f"img{i:03d}.png"), np.clip(np.rint(m), 0, 255).astype(np.uint8))
+        return disps
 
     def spin_iteration(self, *args, **kwargs):
         """spin_loss + backward + all-reduce + Adam; returns (loss, psnr of the unmasked-pixel render)."""

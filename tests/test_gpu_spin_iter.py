@@ -93,3 +93,100 @@ def test_spin_iteration_loss_and_gradients_match_oracle():
     l3, _ = tr.spin_loss(H, W, focal, cu(rays_clf), cu(t_clf), cu(rays_all), cu(t_all), cu(rays_inp),
                          torch.full((N,), float("nan")).cuda())
     assert np.isfinite(float(l3))
+
+
+def test_colmap_depth_render_and_prepare_export_and_lpips_hookup(tmp_path):
+    """The rest of the iteration (run_nerf.py:1473-1507, 1523-1561, 1563-1609): the render with the COLMAP `depths=` column
+    and its depth loss against the oracle (loss value and gradients), the perceptual term's patch renders with a stand-in
+    distance, and the --prepare disparity export."""
+    import spin_nerf_amd as S
+    train = importlib.import_module("spin-nerf_amd.train")
+    H, W, focal, near, far = 20, 24, 30.0, 2.0, 6.0
+    Nc, Nf, N = 64, 32, 40
+    sd_c, sd_f = O.init_nerf_params(seed=3, gain=2.0), O.init_nerf_params(seed=4, gain=2.0)
+
+    def mk(sd):
+        n = S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True, precision="fp32").cuda()
+        n.load_state_dict(sd)
+        return n
+    net_c, net_f = mk(sd_c), mk(sd_f)
+
+    def q(inputs, viewdirs, network_fn):
+        return S.run_network(inputs, viewdirs, network_fn)
+    q._snr_fused = True
+    kw = dict(network_query_fn=q, perturb=1.0, N_importance=Nf, network_fine=net_f, N_samples=Nc, network_fn=net_c,
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=1.0, ndc=False, lindisp=False, near=near, far=far)
+    tr = train.RenderTrainer(kw, lrate=5e-4)
+    g = torch.Generator().manual_seed(0)
+    c2w = torch.eye(4)[:3, :4].clone(); c2w[2, 3] = 4.0
+    ro, rd = O.get_rays(H, W, focal, c2w)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+
+    def batch():
+        sel = torch.randperm(H * W, generator=g)[:N]
+        return torch.stack([ro[sel], rd[sel]], 0)
+    rays_clf, rays_all, rays_dep = batch(), batch(), batch()
+    t_clf, t_all = torch.rand(N, 3, generator=g), torch.rand(N, 3, generator=g)
+    t_dep = torch.rand(N, generator=g) * 2 + 3
+    wts = torch.rand(N, generator=g)
+
+    def rnd(seed):
+        gg = torch.Generator().manual_seed(seed)
+        return {"t_rand": torch.rand(N, Nc, generator=gg), "u": torch.rand(N, Nf, generator=gg),
+                "noise_c": torch.randn(N, Nc, generator=gg), "noise_f": torch.randn(N, Nc + Nf, generator=gg)}
+    rnds = [rnd(1), rnd(2), None, rnd(4)]
+    cu = lambda t: t.cuda()
+    for mode, ref_term in (("weighted", lambda d: torch.mean(((d - t_dep) ** 2) * wts)),
+                           ("relative", lambda d: torch.mean(((d - t_dep) / t_dep) ** 2)),
+                           ("mse", lambda d: O.img2mse(d, t_dep))):
+        pc = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
+        pf = {k: v.clone().requires_grad_(True) for k, v in sd_f.items()}
+        okw = dict(sd_coarse=pc, sd_fine=pf, N_samples=Nc, N_importance=Nf, perturb=1.0, white_bkgd=False, lindisp=False,
+                   use_viewdirs=True, ndc=False, near=near, far=far, retraw=True)
+        rgb, _, _, _, ex = O.render(H, W, focal, rays=rays_clf, randoms=rnds[0], **okw)
+        rgb_c, _, _, _, ex_c = O.render(H, W, focal, rays=rays_all, randoms=rnds[1], detach_weights=True, **okw)
+        _, _, _, depth_col, _ = O.render(H, W, focal, rays=rays_dep, depths=t_dep, randoms=rnds[3], **okw)
+        ref = (O.img2mse(rgb, t_clf) + O.img2mse(rgb_c, t_all) + O.img2mse(ex_c["rgb0"], t_all) + O.img2mse(ex["rgb0"], t_clf)
+               + 0.1 * ref_term(depth_col))
+        ref.backward()
+        for n in (net_c, net_f):
+            n.flat.grad = None
+        loss, outs = tr.spin_loss(H, W, focal, cu(rays_clf), cu(t_clf), cu(rays_all), cu(t_all),
+                                  randoms=[{k: cu(v) for k, v in r.items()} if r else None for r in rnds],
+                                  colmap_depth=dict(rays=cu(rays_dep), target=cu(t_dep), weights=cu(wts), depth_lambda=0.1,
+                                                    mode=mode))
+        assert abs(float(loss.detach()) - float(ref.detach())) < 5e-4 * abs(float(ref.detach())), (mode, float(loss.detach()), float(ref.detach()))
+        assert tuple(outs["colmap"][0].shape) == (N,)
+        loss.backward()
+        for net, p in ((net_c, pc), (net_f, pf)):
+            got = net.named_views(net.flat.grad)
+            for k, v in p.items():
+                a, b = got[k].cpu().double().reshape(-1), v.grad.double().reshape(-1)
+                rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+                assert rel < 1e-2, f"{mode} {k}: relative L2 error {rel:.2e}"
+
+    # ---- perceptual term: patch renders with gradients, a stand-in distance (mean squared difference per image) ----
+    kw_test = dict(kw, perturb=False, raw_noise_std=0.)
+    poses = torch.stack([c2w, c2w + torch.tensor([[0, 0, 0, 0.2], [0, 0, 0, 0], [0, 0, 0, 0]])]).cuda()
+    images = torch.rand(2, H, W, 3, generator=g).cuda()
+    masks = np.zeros((2, H, W)); masks[:, 4:16, 5:20] = 1
+    calls = []
+
+    def dist_fn(pred, target):
+        assert pred.shape == target.shape == (1, 3, H // 4, W // 4) and pred.requires_grad
+        assert float(pred.detach().abs().max()) <= 1.0 + 1e-5 and float(target.abs().max()) <= 1.0 + 1e-5
+        calls.append(1)
+        return ((pred - target) ** 2).mean(dim=(1, 2, 3))
+    for n in (net_c, net_f):
+        n.flat.grad = None
+    term = tr.lpips_term(dist_fn, poses, images, masks, (H, W, focal), kw_test)
+    assert len(calls) == 2 and 0 < float(term.detach()) < 4.0 / 100 + 1e-6
+    term.backward()
+    assert float(net_f.flat.grad.abs().max()) > 0
+
+    # ---- --prepare: disparity maps and masks for the depth inpainter ----
+    tr.export_disparities(poses, (H, W, focal), kw_test, masks, str(tmp_path / "prep"), render_factor=2)
+    import os
+    assert sorted(os.listdir(tmp_path / "prep")) == ["img000.png", "img001.png", "label"]
+    assert sorted(os.listdir(tmp_path / "prep" / "label")) == ["img000.png", "img001.png"]
+    assert open(tmp_path / "prep" / "img000.png", "rb").read(8) == b"\x89PNG\r\n\x1a\n"
