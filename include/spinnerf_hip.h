@@ -149,6 +149,29 @@ int snr_sample_fine(const float* z_coarse, const float* weights, const float* u,
 int snr_sample_pdf(const float* bins, const float* weights, const float* u, int64_t n_rays, int n_bins,
                    int n_samples, float* samples, snr_stream_t stream);
 
+/* ---- the training step's production forms (run_nerf.py:593-737 + 1482-1490 + autograd's first step): the same
+ * arithmetic with the random draws made in-kernel and the loss folded into the compositing kernel.
+ * Random numbers: Philox4x32-10, element i of a call = counter (i, 0, offset) under key `seed`; the caller advances
+ * `offset` by one per call.  (The reference draws torch.rand / torch.randn, run_nerf.py:660-668, 699 and helpers:376-381;
+ * the entry points above take injected draws and are what the parity tests use.) */
+/* stratified z_vals with t_rand ~ U[0,1) drawn in-kernel */
+int snr_sample_coarse_rng(const float* rays, int ray_ld, int64_t n_rays, int n_samples, int lindisp, uint64_t seed,
+                          uint64_t offset, float* z_vals, snr_stream_t stream);
+/* hierarchical sampling with u ~ U[0,1) drawn in-kernel */
+int snr_sample_fine_rng(const float* z_coarse, const float* weights, int64_t n_rays, int n_coarse, int n_fine,
+                        uint64_t seed, uint64_t offset, float* z_out, float* z_samples, float* z_std,
+                        snr_stream_t stream);
+/* raw2outputs forward + this network's loss term mean((rgb_map - target)^2) over the GLOBAL batch (3 * n_rays_global
+ * elements, so that data-parallel shards sum to the global mean) + the backward of both, in one kernel: maps and weights
+ * as snr_composite_forward, d_raw as snr_composite_backward would give for g_rgb = d loss / d rgb_map.  Density noise:
+ * `noise` [n_rays,S] pre-scaled, or NULL with noise_std > 0 = N(0,1) * noise_std drawn in-kernel (the same numbers in the
+ * forward and the backward half).  loss[0] += the term, and loss_also[0] too when non-NULL (zero them first). */
+int snr_composite_train(const float* raw, int raw_ch, const float* z_vals, const float* rays, int ray_ld,
+                        const float* noise, float noise_std, uint64_t seed, uint64_t offset, int64_t n_rays, int S,
+                        int white_bkgd, int detach_weights, const float* target, int64_t n_rays_global, float* rgb_map,
+                        float* disp_map, float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss,
+                        float* loss_also, snr_stream_t stream);
+
 /* ---- rays: replaces get_rays + ndc_rays + the ray packing of render() (helpers:249-300,
  * run_nerf.py:117-153).  Writes rows [o(3) d(3) near far (viewdirs(3))] for the pixel rectangle
  * [i0,i0+h) x [j0,j0+w) of an H x W pinhole camera with pose c2w_host (12 floats, HOST memory). */

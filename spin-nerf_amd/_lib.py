@@ -54,6 +54,10 @@ SIGNATURES = {
     "snr_composite_forward": (_i, [_p, _i, _p, _p, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "snr_composite_backward": (_i, [_p, _i, _p, _p, _i, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "snr_sample_fine": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p, _p]),
+    "snr_sample_coarse_rng": (_i, [_p, _i, _l, _i, _i, _c.c_uint64, _c.c_uint64, _p, _p]),
+    "snr_sample_fine_rng": (_i, [_p, _p, _l, _i, _i, _c.c_uint64, _c.c_uint64, _p, _p, _p, _p]),
+    "snr_composite_train": (_i, [_p, _i, _p, _p, _i, _p, _f, _c.c_uint64, _c.c_uint64, _l, _i, _i, _i, _p, _l, _p, _p, _p, _p,
+                                 _p, _p, _p, _p, _p]),
     "snr_make_rays": (_i, [_i, _i, _f, _c.POINTER(_f), _i, _i, _i, _i, _i, _f, _f, _i, _p, _i, _p]),
     "snr_sample_pdf": (_i, [_p, _p, _p, _l, _i, _i, _p, _p]),
     "snr_pack_rays": (_i, [_p, _p, _p, _l, _i, _i, _f, _i, _f, _f, _f, _p, _p, _p, _i, _p, _i, _p]),

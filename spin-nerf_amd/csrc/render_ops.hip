@@ -51,6 +51,39 @@ __device__ __forceinline__ float linspace01(int i, int n) {
 }
 
 // ------------------------------------------------------------------------------------------
+// counter-based random numbers for the production path (the reference draws torch.rand / torch.randn,
+// run_nerf.py:660-668, helpers:376-381; parity tests inject their draws instead): Philox4x32-10, element i of a
+// call = counter (i, 0, offset_lo, offset_hi) under key (seed_lo, seed_hi) — no state, no generator launch, and a
+// backward pass re-derives the forward's noise from the same (seed, offset) instead of reading it back from HBM.
+// ------------------------------------------------------------------------------------------
+struct Rng { uint32_t seed_lo, seed_hi, off_lo, off_hi; };
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+// U[0, 1) with 24 random bits (torch.rand's range)
+__device__ __forceinline__ float rng_uniform(const Rng& g, int64_t i) {
+  uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), g.off_lo, g.off_hi};
+  philox4x32_10(c, g.seed_lo, g.seed_hi);
+  return (float)(c[0] >> 8) * 5.9604644775390625e-8f;
+}
+// N(0, 1): Box-Muller on two words of one block
+__device__ __forceinline__ float rng_normal(const Rng& g, int64_t i) {
+  uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), g.off_lo, g.off_hi};
+  philox4x32_10(c, g.seed_lo, g.seed_hi);
+  const float u1 = (float)((c[0] >> 8) + 1u) * 5.9604644775390625e-8f;   // (0, 1]
+  const float u2 = (float)(c[1] >> 8) * 5.9604644775390625e-8f;
+  return sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
+}
+
+// ------------------------------------------------------------------------------------------
 // stratified sampling (run_nerf.py:646-668)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float z_at(float near, float far, int i, int n, int lindisp) {
@@ -60,19 +93,20 @@ __device__ __forceinline__ float z_at(float near, float far, int i, int n, int l
 }
 
 __global__ void sample_coarse_kernel(const float* __restrict__ rays, int ld, int64_t n_rays, int N, int lindisp,
-                                     const float* __restrict__ t_rand, float* __restrict__ z_vals) {
+                                     const float* __restrict__ t_rand, int use_rng, Rng rng,
+                                     float* __restrict__ z_vals) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_rays * N) return;
   const int64_t r = idx / N;
   const int i = (int)(idx - r * N);
   const float near = rays[r * ld + 6], far = rays[r * ld + 7];
   const float z = z_at(near, far, i, N, lindisp);
-  if (!t_rand) { z_vals[idx] = z; return; }
+  if (!t_rand && !use_rng) { z_vals[idx] = z; return; }
   const float zl = i > 0 ? z_at(near, far, i - 1, N, lindisp) : z;
   const float zu = i < N - 1 ? z_at(near, far, i + 1, N, lindisp) : z;
   const float lower = i > 0 ? .5f * (z + zl) : z;       // run_nerf.py:656-658
   const float upper = i < N - 1 ? .5f * (zu + z) : z;
-  z_vals[idx] = lower + (upper - lower) * t_rand[idx];  // run_nerf.py:668
+  z_vals[idx] = lower + (upper - lower) * (t_rand ? t_rand[idx] : rng_uniform(rng, idx));  // run_nerf.py:668
 }
 
 // ------------------------------------------------------------------------------------------
@@ -81,17 +115,18 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, int ld, int
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void composite_fwd_kernel(
-    const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
-    const float* __restrict__ noise, int64_t n_rays, int S, int white, float* __restrict__ rgb_map,
-    float* __restrict__ disp_map, float* __restrict__ acc_map, float* __restrict__ depth_map,
-    float* __restrict__ weights, float* __restrict__ alpha_out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
-  if (ray >= n_rays) return;
-  const float* rd = rays + ray * ld + 3;
-  const float dn = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);  // torch.norm
-  const float* zr = z_vals + ray * S;
+// density noise of sample e = ray * S + i: an array the caller drew (pre-scaled), the in-kernel generator, or none
+struct NoiseSrc { const float* arr; int use_rng; Rng rng; float std; };
+__device__ __forceinline__ float noise_at(const NoiseSrc& ns, int64_t e) {
+  return ns.arr ? ns.arr[e] : (ns.use_rng ? rng_normal(ns.rng, e) * ns.std : 0.f);
+}
+
+struct CompMaps { float r, g, b, disp, acc, depth; };   // the same values in every lane
+
+// forward of one ray by one wave: weights (and alpha) to memory, the maps returned
+__device__ __forceinline__ CompMaps composite_fwd_ray(const float* __restrict__ raw, int C, const float* __restrict__ zr,
+                                                      float dn, const NoiseSrc& ns, int64_t ray, int S, int white, int lane,
+                                                      float* __restrict__ weights, float* __restrict__ alpha_out) {
   float T = 1.f;  // transmittance entering this chunk
   float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
   for (int base = 0; base < S; base += kWave) {
@@ -104,8 +139,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
       dist = dist * dn;                                     // helpers:369
       const float* rw = raw + (ray * S + i) * C;
       c0 = sigmoidf(rw[0]); c1 = sigmoidf(rw[1]); c2 = sigmoidf(rw[2]);
-      float s = rw[3];
-      if (noise) s += noise[ray * S + i];
+      const float s = rw[3] + noise_at(ns, ray * S + i);
       const float a = 1.f - expf(-fmaxf(s, 0.f) * dist);  // helpers:364,382
       if (alpha_out) alpha_out[ray * S + i] = a;
       one_m = 1.f - a + 1e-10f;
@@ -120,34 +154,38 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     sr += w * c0; sg += w * c1; sb += w * c2; sd += w * z; sa += w;
   }
   sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+  const float q = sd / sa;
+  // torch.max(1e-10, q) propagates NaN (helpers:391)
+  const float disp = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
+  if (white) { sr += 1.f - sa; sg += 1.f - sa; sb += 1.f - sa; }  // helpers:394-395
+  return CompMaps{sr, sg, sb, disp, sa, sd};
+}
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(
+    const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
+    NoiseSrc ns, int64_t n_rays, int S, int white, float* __restrict__ rgb_map,
+    float* __restrict__ disp_map, float* __restrict__ acc_map, float* __restrict__ depth_map,
+    float* __restrict__ weights, float* __restrict__ alpha_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const float* rd = rays + ray * ld + 3;
+  const float dn = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);  // torch.norm
+  const CompMaps m = composite_fwd_ray(raw, C, z_vals + ray * S, dn, ns, ray, S, white, lane, weights, alpha_out);
   if (lane == 0) {
-    const float q = sd / sa;
-    // torch.max(1e-10, q) propagates NaN (helpers:391)
-    const float disp = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
-    if (white) { sr += 1.f - sa; sg += 1.f - sa; sb += 1.f - sa; }  // helpers:394-395
-    rgb_map[3 * ray] = sr; rgb_map[3 * ray + 1] = sg; rgb_map[3 * ray + 2] = sb;
-    disp_map[ray] = disp; acc_map[ray] = sa; depth_map[ray] = sd;
+    rgb_map[3 * ray] = m.r; rgb_map[3 * ray + 1] = m.g; rgb_map[3 * ray + 2] = m.b;
+    disp_map[ray] = m.disp; acc_map[ray] = m.acc; depth_map[ray] = m.depth;
   }
 }
 
-// Backward.  With G_i = dL/dw_i, dL/dalpha_i = G_i T_i - (sum_{j>i} G_j w_j) / (1 - alpha_i + 1e-10)
+// Backward of one ray.  With G_i = dL/dw_i, dL/dalpha_i = G_i T_i - (sum_{j>i} G_j w_j) / (1 - alpha_i + 1e-10)
 // (the cumprod backward torch uses when no factor is exactly 0), plus the direct g_alpha term.
-__global__ __launch_bounds__(256) void composite_bwd_kernel(
-    const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
-    const float* __restrict__ noise, int64_t n_rays, int S, int white, int detach, const float* __restrict__ g_rgb,
-    const float* __restrict__ g_disp, const float* __restrict__ g_acc, const float* __restrict__ g_depth,
-    const float* __restrict__ g_w, const float* __restrict__ g_alpha, float* __restrict__ d_raw) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
-  if (ray >= n_rays) return;
-  const float* rd = rays + ray * ld + 3;
-  const float dn = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
-  const float* zr = z_vals + ray * S;
-  const float gr = g_rgb ? g_rgb[3 * ray] : 0.f, gg = g_rgb ? g_rgb[3 * ray + 1] : 0.f,
-              gb = g_rgb ? g_rgb[3 * ray + 2] : 0.f;
-  const float gD = g_depth ? g_depth[ray] : 0.f, gA = g_acc ? g_acc[ray] : 0.f, gP = g_disp ? g_disp[ray] : 0.f;
+__device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ raw, int C, const float* __restrict__ zr,
+                                                  float dn, const NoiseSrc& ns, int64_t ray, int S, int white, int detach,
+                                                  float gr, float gg, float gb, float gD, float gA, float gP,
+                                                  const float* __restrict__ g_w, const float* __restrict__ g_alpha,
+                                                  float* __restrict__ d_raw, int lane) {
   const int nchunks = (S + kWave - 1) / kWave;
-
   // pass 1: recompute w, accumulate acc/depth (needed for the disparity term)
   float T = 1.f, sd = 0.f, sa = 0.f;
   for (int base = 0; base < S; base += kWave) {
@@ -156,8 +194,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     if (i < S) {
       z = zr[i];
       const float dist = ((i + 1 < S) ? (zr[i + 1] - z) : 1e10f) * dn;
-      float s = raw[(ray * S + i) * C + 3];
-      if (noise) s += noise[ray * S + i];
+      const float s = raw[(ray * S + i) * C + 3] + noise_at(ns, ray * S + i);
       a = 1.f - expf(-fmaxf(s, 0.f) * dist);
       one_m = 1.f - a + 1e-10f;
     }
@@ -184,8 +221,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
       const int i2 = b2 + lane;
       const float z2 = zr[i2];
       const float dist2 = ((i2 + 1 < S) ? (zr[i2 + 1] - z2) : 1e10f) * dn;
-      float s2 = raw[(ray * S + i2) * C + 3];
-      if (noise) s2 += noise[ray * S + i2];
+      const float s2 = raw[(ray * S + i2) * C + 3] + noise_at(ns, ray * S + i2);
       const float a2 = 1.f - expf(-fmaxf(s2, 0.f) * dist2);
       const float incl2 = wave_incl_scan_mul(1.f - a2 + 1e-10f, lane);
       Tin = Tin * __shfl(incl2, kWave - 1, kWave);
@@ -198,8 +234,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
       dist = ((i + 1 < S) ? (zr[i + 1] - z) : 1e10f) * dn;
       const float* rw = raw + (ray * S + i) * C;
       r0 = rw[0]; r1 = rw[1]; r2 = rw[2];
-      s = rw[3];
-      if (noise) s += noise[ray * S + i];
+      s = rw[3] + noise_at(ns, ray * S + i);
       a = 1.f - expf(-fmaxf(s, 0.f) * dist);
       one_m = 1.f - a + 1e-10f;
     }
@@ -232,6 +267,60 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
   }
 }
 
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
+    NoiseSrc ns, int64_t n_rays, int S, int white, int detach, const float* __restrict__ g_rgb,
+    const float* __restrict__ g_disp, const float* __restrict__ g_acc, const float* __restrict__ g_depth,
+    const float* __restrict__ g_w, const float* __restrict__ g_alpha, float* __restrict__ d_raw) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+  if (ray >= n_rays) return;
+  const float* rd = rays + ray * ld + 3;
+  const float dn = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
+  const float gr = g_rgb ? g_rgb[3 * ray] : 0.f, gg = g_rgb ? g_rgb[3 * ray + 1] : 0.f,
+              gb = g_rgb ? g_rgb[3 * ray + 2] : 0.f;
+  const float gD = g_depth ? g_depth[ray] : 0.f, gA = g_acc ? g_acc[ray] : 0.f, gP = g_disp ? g_disp[ray] : 0.f;
+  composite_bwd_ray(raw, C, z_vals + ray * S, dn, ns, ray, S, white, detach, gr, gg, gb, gD, gA, gP, g_w, g_alpha, d_raw,
+                    lane);
+}
+
+// One kernel per network of the TRAINING step: compositing forward, the loss term mean((rgb - target)^2) of this
+// network's colour map with its gradient (img2mse, helpers:15; run_nerf.py:1482-1490), and the compositing backward —
+// render_rays' tail and autograd's head without the rgb / gradient round trip and two extra launches.  inv_count =
+// 1 / (3 * rays of the GLOBAL batch); loss[slot] += this call's term (atomics, one per workgroup).
+__global__ __launch_bounds__(256) void composite_train_kernel(
+    const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
+    NoiseSrc ns, int64_t n_rays, int S, int white, int detach, const float* __restrict__ target, float inv_count,
+    float* __restrict__ rgb_map, float* __restrict__ disp_map, float* __restrict__ acc_map,
+    float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, float* __restrict__ loss,
+    float* __restrict__ loss_also) {
+  __shared__ float sq[kRaysPerBlock];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+  float e2 = 0.f;
+  if (ray < n_rays) {
+    const float* rd = rays + ray * ld + 3;
+    const float dn = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
+    const CompMaps m = composite_fwd_ray(raw, C, z_vals + ray * S, dn, ns, ray, S, white, lane, weights, nullptr);
+    if (lane == 0) {
+      rgb_map[3 * ray] = m.r; rgb_map[3 * ray + 1] = m.g; rgb_map[3 * ray + 2] = m.b;
+      disp_map[ray] = m.disp; acc_map[ray] = m.acc; depth_map[ray] = m.depth;
+    }
+    const float dr = m.r - target[3 * ray], dg = m.g - target[3 * ray + 1], db = m.b - target[3 * ray + 2];
+    e2 = dr * dr + dg * dg + db * db;
+    composite_bwd_ray(raw, C, z_vals + ray * S, dn, ns, ray, S, white, detach, 2.f * dr * inv_count, 2.f * dg * inv_count,
+                      2.f * db * inv_count, 0.f, 0.f, 0.f, nullptr, nullptr, d_raw, lane);
+  }
+  if (lane == 0) sq[wv] = e2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kRaysPerBlock; ++w) t += sq[w];
+    atomicAdd(loss, t * inv_count);
+    if (loss_also) atomicAdd(loss_also, t * inv_count);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // hierarchical sampling (helpers:304-347) + sort of the union (run_nerf.py:702) + z_std (:726)
 // one wave per ray; LDS per wave: cdf[Nc-1], bins[Nc-1], sort buffer[pow2 >= Nc+Nf]
@@ -241,7 +330,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
                                                           const float* __restrict__ u_in, int64_t n_rays, int Nc, int Nf,
                                                           int npow2, float* __restrict__ z_out,
                                                           float* __restrict__ z_samples, float* __restrict__ z_std,
-                                                          int direct) {
+                                                          int direct, int use_rng, Rng rng) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
@@ -279,7 +368,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
 
   float sum = 0.f;
   for (int k = lane; k < Nf; k += kWave) {
-    const float u = u_in ? u_in[ray * Nf + k] : linspace01(k, Nf);  // helpers:313
+    const float u = u_in ? u_in[ray * Nf + k] : (use_rng ? rng_uniform(rng, ray * Nf + k) : linspace01(k, Nf));  // helpers:313-316
     // inds = searchsorted(cdf, u, right=True) = #{cdf <= u}
     int lo = 0, hi = nb;
     while (lo < hi) {
@@ -494,7 +583,7 @@ extern "C" int snr_sample_coarse(const float* rays, int ld, int64_t n_rays, int 
   {
     ProfScope ps(K_SAMPLE_COARSE, (hipStream_t)stream);
     sample_coarse_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        rays, ld, n_rays, N, lindisp, t_rand, z_vals);
+        rays, ld, n_rays, N, lindisp, t_rand, 0, Rng{}, z_vals);
   }
   return launch_status();
 }
@@ -508,9 +597,9 @@ extern "C" int snr_composite_forward(const float* raw, int C, const float* z, co
   const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   {
     ProfScope ps(K_COMPOSITE_FWD, (hipStream_t)stream);
-    composite_fwd_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(raw, C, z, rays, ld, noise, n_rays, S, white,
-                                                                            rgb_map, disp_map, acc_map, depth_map,
-                                                                            weights, alpha);
+    composite_fwd_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(raw, C, z, rays, ld, NoiseSrc{noise, 0, Rng{}, 0.f},
+                                                                            n_rays, S, white, rgb_map, disp_map, acc_map,
+                                                                            depth_map, weights, alpha);
   }
   return launch_status();
 }
@@ -526,7 +615,8 @@ extern "C" int snr_composite_backward(const float* raw, int C, const float* z, c
   {
     ProfScope ps(K_COMPOSITE_BWD, (hipStream_t)stream);
     composite_bwd_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(
-        raw, C, z, rays, ld, noise, n_rays, S, white, detach, g_rgb, g_disp, g_acc, g_depth, g_w, g_alpha, d_raw);
+        raw, C, z, rays, ld, NoiseSrc{noise, 0, Rng{}, 0.f}, n_rays, S, white, detach, g_rgb, g_disp, g_acc, g_depth, g_w,
+        g_alpha, d_raw);
   }
   return launch_status();
 }
@@ -548,7 +638,7 @@ extern "C" int snr_sample_fine(const float* z_coarse, const float* weights, cons
   {
     ProfScope ps(K_SAMPLE_FINE, (hipStream_t)stream);
     sample_fine_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(z_coarse, weights, u, n_rays, Nc, Nf, npow2,
-                                                                            z_out, z_samples, z_std, 0);
+                                                                            z_out, z_samples, z_std, 0, 0, Rng{});
   }
   return launch_status();
 }
@@ -571,7 +661,67 @@ extern "C" int snr_sample_pdf(const float* bins, const float* weights, const flo
   {
     ProfScope ps(K_SAMPLE_FINE, (hipStream_t)stream);
     sample_fine_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(bins, weights, u, n_rays, Nc, n_samples, npow2,
-                                                                            nullptr, samples, nullptr, 1);
+                                                                            nullptr, samples, nullptr, 1, 0, Rng{});
+  }
+  return launch_status();
+}
+
+static Rng make_rng(uint64_t seed, uint64_t offset) {
+  return Rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+}
+
+extern "C" int snr_sample_coarse_rng(const float* rays, int ld, int64_t n_rays, int N, int lindisp, uint64_t seed,
+                                     uint64_t offset, float* z_vals, snr_stream_t stream) {
+  SNR_CHECK_ARG(rays && z_vals, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_rays > 0 && N > 0 && ld >= 8, SNR_ERR_SHAPE);
+  const int64_t n = n_rays * N;
+  {
+    ProfScope ps(K_SAMPLE_COARSE, (hipStream_t)stream);
+    sample_coarse_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        rays, ld, n_rays, N, lindisp, nullptr, 1, make_rng(seed, offset), z_vals);
+  }
+  return launch_status();
+}
+
+extern "C" int snr_sample_fine_rng(const float* z_coarse, const float* weights, int64_t n_rays, int Nc, int Nf,
+                                   uint64_t seed, uint64_t offset, float* z_out, float* z_samples, float* z_std,
+                                   snr_stream_t stream) {
+  SNR_CHECK_ARG(z_coarse && weights && z_out, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_rays > 0 && Nc >= 3 && Nf >= 1 && Nc + Nf <= 4096, SNR_ERR_SHAPE);
+  int npow2 = 2;
+  while (npow2 < Nc + Nf) npow2 <<= 1;
+  const size_t lds = (size_t)kRaysPerBlock * (2 * (Nc - 1) + npow2) * sizeof(float);
+  SNR_CHECK_ARG(lds <= 160 * 1024, SNR_ERR_SHAPE);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)sample_fine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  {
+    ProfScope ps(K_SAMPLE_FINE, (hipStream_t)stream);
+    sample_fine_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(z_coarse, weights, nullptr, n_rays, Nc, Nf, npow2,
+                                                                            z_out, z_samples, z_std, 0, 1,
+                                                                            make_rng(seed, offset));
+  }
+  return launch_status();
+}
+
+extern "C" int snr_composite_train(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
+                                   float noise_std, uint64_t seed, uint64_t offset, int64_t n_rays, int S, int white,
+                                   int detach, const float* target, int64_t n_rays_global, float* rgb_map,
+                                   float* disp_map, float* acc_map, float* depth_map, float* weights, float* d_raw,
+                                   float* loss, float* loss_also, snr_stream_t stream) {
+  SNR_CHECK_ARG(raw && z && rays && target && rgb_map && disp_map && acc_map && depth_map && weights && d_raw && loss,
+                SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_rays > 0 && n_rays_global >= n_rays && S > 0 && C >= 4 && ld >= 6, SNR_ERR_SHAPE);
+  const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  const NoiseSrc ns{noise, (!noise && noise_std > 0.f) ? 1 : 0, make_rng(seed, offset), noise_std};
+  {
+    ProfScope ps(K_COMPOSITE_FWD, (hipStream_t)stream);
+    composite_train_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(
+        raw, C, z, rays, ld, ns, n_rays, S, white, detach, target, 1.f / (3.f * (float)n_rays_global), rgb_map, disp_map,
+        acc_map, depth_map, weights, d_raw, loss, loss_also);
   }
   return launch_status();
 }

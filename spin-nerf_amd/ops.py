@@ -292,6 +292,75 @@ def mlp_query(net, pts=None, rays=None, z_vals=None, viewdirs=None, samples_per_
 
 
 # ----------------------------------------------------------------------------------------------
+# the training step's production forms: in-kernel random draws, loss folded into the compositing kernel
+# ----------------------------------------------------------------------------------------------
+def sample_coarse_rng(ray_batch, N_samples, lindisp, seed, offset):
+    lib = _lib.load()
+    n = ray_batch.shape[0]
+    z = torch.empty(n, N_samples, device=ray_batch.device, dtype=torch.float32)
+    check(lib.snr_sample_coarse_rng(ptr(ray_batch), ray_batch.shape[1], n, N_samples, int(bool(lindisp)), int(seed),
+                                    int(offset), ptr(z), stream()), "snr_sample_coarse_rng")
+    return z
+
+
+def sample_fine_rng(z_coarse, weights, N_importance, seed, offset):
+    lib = _lib.load()
+    n, nc = z_coarse.shape
+    z_out = torch.empty(n, nc + N_importance, device=z_coarse.device, dtype=torch.float32)
+    check(lib.snr_sample_fine_rng(ptr(z_coarse), ptr(weights), n, nc, N_importance, int(seed), int(offset), ptr(z_out),
+                                  None, None, stream()), "snr_sample_fine_rng")
+    return z_out
+
+
+def composite_train(raw, z_vals, rays, target, loss, loss_also=None, noise=None, noise_std=0., seed=0, offset=0,
+                    white_bkgd=False, detach_weights=False):
+    """raw2outputs + mean((rgb_map - target)^2) + the backward of both in one launch -> (rgb, disp, acc, depth, weights,
+    d loss / d raw); the loss term is added to loss[0] (and loss_also[0])."""
+    lib = _lib.load()
+    n, S, C = raw.shape
+    dev = raw.device
+    rgb = torch.empty(n, 3, device=dev); disp = torch.empty(n, device=dev); acc = torch.empty(n, device=dev)
+    depth = torch.empty(n, device=dev); w = torch.empty(n, S, device=dev); d_raw = torch.empty_like(raw)
+    check(lib.snr_composite_train(ptr(raw), C, ptr(z_vals), ptr(rays), rays.shape[1], ptr(noise), float(noise_std),
+                                  int(seed), int(offset), n, S, int(bool(white_bkgd)), int(bool(detach_weights)),
+                                  ptr(target), n, ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(w), ptr(d_raw), ptr(loss),
+                                  ptr(loss_also), stream()), "snr_composite_train")
+    return rgb, disp, acc, depth, w, d_raw
+
+
+def mlp_train_forward(net, rays, z_vals, viewdirs):
+    """NeRF forward for the autograd-free training step: (raw [N,S,C], saved context for mlp_train_backward)."""
+    lib = _lib.load()
+    cfg = net.cfg
+    packed = net.packed_weights()
+    n = z_vals.numel()
+    raw = torch.empty(z_vals.shape[0], z_vals.shape[1], cfg.out_ch, device=z_vals.device, dtype=torch.float32)
+    nbytes = lib.snr_mlp_act_bytes(cfg, n)
+    if nbytes <= 0:
+        check(int(nbytes), "snr_mlp_act_bytes")
+    act = torch.empty(nbytes, device=z_vals.device, dtype=torch.uint8)
+    vd = viewdirs if cfg.use_viewdirs else None
+    check(lib.snr_mlp_forward(cfg, ptr(packed), None, ptr(rays), rays.shape[1], ptr(z_vals), ptr(vd),
+                              vd.stride(0) if vd is not None else 0, n, z_vals.shape[1], ptr(raw), ptr(act), stream()),
+          "snr_mlp_forward")
+    return raw, (packed, act, n)
+
+
+def mlp_train_backward(net, saved, d_raw):
+    lib = _lib.load()
+    packed, act, n = saved
+    cfg = net.cfg
+    g = torch.empty_like(net.flat.data)
+    ws_bytes = lib.snr_mlp_bwd_ws_bytes(cfg, n)
+    if ws_bytes <= 0:
+        check(int(ws_bytes), "snr_mlp_bwd_ws_bytes")
+    ws = torch.empty(ws_bytes, device=g.device, dtype=torch.uint8)
+    check(lib.snr_mlp_backward(cfg, ptr(packed), ptr(net.flat.detach()), ptr(d_raw), n, ptr(act), ptr(ws), ptr(g), 0,
+                               stream()), "snr_mlp_backward")
+    return g
+
+
+# ----------------------------------------------------------------------------------------------
 # Adam on a flat buffer (run_nerf.py:433-434)
 # ----------------------------------------------------------------------------------------------
 def adam_step_(params, grads, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):

@@ -10,6 +10,8 @@ replica of both MLPs (2 x 2.4 MB), and the only collective is one all-reduce of 
 gradient buffer per step over RCCL ("nccl" backend); Adam then runs on the flat buffers with the
 1/world_size scale folded into the kernel.
 """
+import os
+
 import torch
 
 from . import ops
@@ -35,6 +37,9 @@ class RenderTrainer:
         self._lr = lrate              # rate the NEXT step uses (run_nerf.py:1616-1622 sets it after each step)
         self.m = [torch.zeros_like(n.flat.data) for n in self.nets]
         self.v = [torch.zeros_like(n.flat.data) for n in self.nets]
+        # in-kernel random draws (Philox key / running call counter); ranks draw different streams
+        self._seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (self._rank() + 1)) & 0xFFFFFFFFFFFFFFFF
+        self._draws = 0
         if optimizer is not None:
             self._adopt(optimizer, start)
         # The all-reduce of a net's gradient starts the moment autograd has finished that net (the fine net's
@@ -43,6 +48,13 @@ class RenderTrainer:
         if world_size > 1:
             for i, n in enumerate(self.nets):
                 n.flat.register_post_accumulate_grad_hook(lambda p, i=i: self._start_all_reduce(i, p))
+
+    def _rank(self):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return dist.get_rank(self.pg)
+        return 0
 
     def _start_all_reduce(self, i, p):
         import torch.distributed as dist
@@ -81,7 +93,14 @@ class RenderTrainer:
         return self._lr
 
     def step(self, H, W, focal, batch_rays, target_s, chunk=1024 * 32, **extra):
-        """one optimisation step on this rank's ray shard; returns (loss, rgb) detached"""
+        """one optimisation step on this rank's ray shard; returns (loss, rgb) detached.
+
+        The plain configuration (NeRF networks, no sigma_loss / pytest hook, one chunk) runs without torch autograd:
+        every launch of run_nerf.py:1465-1490 + 1611-1612 is issued directly, the random draws are made in-kernel
+        (or taken from ``randoms=``), and each network's compositing forward, loss term and compositing backward are
+        one kernel (snr_composite_train).  Anything else goes through render() + autograd."""
+        if self._direct_ok(batch_rays, chunk, extra):
+            return self._step_direct(H, W, focal, batch_rays, target_s, extra.get("randoms"))
         for n in self.nets:
             n.flat.grad = None
         rgb, disp, acc, depth, extras = render(H, W, focal, chunk=chunk, rays=batch_rays, retraw=True,
@@ -96,6 +115,74 @@ class RenderTrainer:
             torch.autograd.backward([rgb], [g_rgb])
         self.apply_gradients()
         return loss, rgb.detach()
+
+    # ---- the autograd-free step ------------------------------------------------------------------------------------
+    def _direct_ok(self, batch_rays, chunk, extra):
+        from .nerf import NeRF
+        kw = self.kw
+        if os.environ.get("SNR_NO_DIRECT_STEP") == "1" or set(extra) - {"randoms"}:
+            return False
+        nets = [kw.get('network_fn')] + ([kw.get('network_fine')] if kw.get('N_importance', 0) > 0 else [])
+        if any(type(n) is not NeRF for n in nets) or kw.get('sigma_loss') is not None:
+            return False
+        if not getattr(kw.get('network_query_fn'), "_snr_fused", False) or not batch_rays[1].is_cuda:
+            return False
+        if isinstance(kw.get('near'), torch.Tensor) or isinstance(kw.get('far'), torch.Tensor):
+            return False
+        return batch_rays.shape[1] <= chunk and bool(kw.get('use_viewdirs')) == bool(nets[0].use_viewdirs)
+
+    def _step_direct(self, H, W, focal, batch_rays, target_s, randoms):
+        kw = self.kw
+        rnd = randoms or {}
+        Nc, Nf = kw['N_samples'], kw.get('N_importance', 0)
+        perturb, std = kw.get('perturb', 0.), float(kw.get('raw_noise_std', 0.))
+        white, lindisp = kw.get('white_bkgd', False), kw.get('lindisp', False)
+        net_c = kw['network_fn']
+        net_f = (kw.get('network_fine') or net_c) if Nf > 0 else None
+        rays = ops.pack_rays(batch_rays[0], batch_rays[1], H, W, focal, ndc=kw.get('ndc', True), near=float(kw.get('near', 0.)),
+                             far=float(kw.get('far', 1.)), use_viewdirs=kw.get('use_viewdirs', False))
+        vd = rays[:, -3:] if rays.shape[1] > 9 else None
+        target = ops.f32c(target_s)
+        loss = torch.zeros(2, device=rays.device)      # [0] = the step's loss, [1] = the final render's term alone
+        seed = self._seed
+
+        def draw():
+            self._draws += 1
+            return self._draws
+
+        # coarse pass (run_nerf.py:646-692)
+        if perturb > 0.:
+            z_c = ops.sample_coarse(rays, Nc, lindisp, rnd["t_rand"]) if rnd.get("t_rand") is not None \
+                else ops.sample_coarse_rng(rays, Nc, lindisp, seed, draw())
+        else:
+            z_c = ops.sample_coarse(rays, Nc, lindisp, None)
+        raw_c, sv_c = ops.mlp_train_forward(net_c, rays, z_c, vd)
+        n_c = ops.f32c(rnd["noise_c"]) if rnd.get("noise_c") is not None else None
+        out_c = ops.composite_train(raw_c, z_c, rays, target, loss[0:1], None if Nf > 0 else loss[1:2], noise=n_c,
+                                    noise_std=std, seed=seed, offset=draw(), white_bkgd=white)
+        rgb = out_c[0]
+        if Nf > 0:                                      # run_nerf.py:694-713
+            if rnd.get("u") is not None:
+                z_f = ops.sample_fine(z_c, out_c[4], Nf, rnd["u"])[0]
+            elif perturb > 0.:
+                z_f = ops.sample_fine_rng(z_c, out_c[4], Nf, seed, draw())
+            else:
+                z_f = ops.sample_fine(z_c, out_c[4], Nf, None)[0]
+            raw_f, sv_f = ops.mlp_train_forward(net_f, rays, z_f, vd)
+            n_f = ops.f32c(rnd["noise_f"]) if rnd.get("noise_f") is not None else None
+            out_f = ops.composite_train(raw_f, z_f, rays, target, loss[0:1], loss[1:2], noise=n_f, noise_std=std, seed=seed,
+                                        offset=draw(), white_bkgd=white)
+            rgb = out_f[0]
+            g_f = ops.mlp_train_backward(net_f, sv_f, out_f[5])
+            g_c = ops.mlp_train_backward(net_c, sv_c, out_c[5])
+            if net_f is net_c:
+                net_c.flat.grad = g_c + g_f
+            else:
+                net_f.flat.grad, net_c.flat.grad = g_f, g_c
+        else:
+            net_c.flat.grad = ops.mlp_train_backward(net_c, sv_c, out_c[5])
+        self.apply_gradients()
+        return loss[0], rgb
 
     def spin_loss(self, H, W, focal, batch_rays_clf, target_clf, batch_rays, target_s, batch_inp=None,
                   depth_inp=None, chunk=1024 * 32, randoms=None, batched=False, colmap_depth=None, lpips=None, **extra):

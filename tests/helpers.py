@@ -50,3 +50,27 @@ def mlp_case_params(g):
     vd = bool(g["use_viewdirs"])
     kw = dict(use_viewdirs=vd, output_ch=4 if vd else 5, input_ch_views=27 if vd else 0)
     return O.make_wild_params(seed=1, **kw) if int(g["wild"]) else O.init_nerf_params(seed=0, **kw)
+
+
+# ---- Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11), numpy restatement of the
+# generator the production kernels draw from (render_ops.hip: rng_uniform / rng_normal) ------------------------------
+def philox4x32_10(ctr, key):
+    """ctr uint32 [..., 4], key (k0, k1) -> uint32 [..., 4]"""
+    c = np.array(ctr, dtype=np.uint64)
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[..., 0], M1 * c[..., 2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+        c = np.stack([hi1 ^ c[..., 1] ^ k0, lo1, hi0 ^ c[..., 3] ^ k1, lo0], -1)
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & MASK, (k1 + np.uint64(0xBB67AE85)) & MASK
+    return c.astype(np.uint32)
+
+
+def philox_uniform(n, seed, offset):
+    """element i of a call: counter (i, 0, offset_lo, offset_hi), key (seed_lo, seed_hi); U[0,1) from 24 bits of word 0"""
+    i = np.arange(n, dtype=np.uint64)
+    ctr = np.stack([i & np.uint64(0xFFFFFFFF), i >> np.uint64(32), np.full(n, offset & 0xFFFFFFFF, np.uint64),
+                    np.full(n, offset >> 32, np.uint64)], -1)
+    w = philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32))
+    return ((w[:, 0] >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)), w

@@ -81,16 +81,20 @@ def train(precision, iters, n_rand=1024, seed=0, white=False, noise=1.0):
 @pytest.mark.timeout(900)
 def test_bf16_training_matches_fp32_psnr():
     """Black background + raw_noise_std=1 (the reference's config value; without the density noise a
-    ReLU-density NeRF collapses to 'empty space' on this scene in ANY precision).  Measured on MI355X,
-    1000 iterations, seeds 0..2: fp32 27.3-27.8 dB, bf16 27.5-28.0 dB — the two paths are
-    indistinguishable within the +-0.35 dB seed-to-seed spread, which is what the 0.7 dB gate encodes
-    (the +-0.1 dB of BASELINE.json needs the statue data and longer runs)."""
-    iters = 1000
+    ReLU-density NeRF collapses to 'empty space' on this scene in ANY precision).
+
+    The per-step training PSNR of this scene swings by +-1.2 dB (standard deviation of a 50-step mean across seeds), so the
+    comparison is made on a long window.  Measured on MI355X (tests/probes/psnr_gap.py, profiles/r02_psnr_gap.txt): 4000
+    iterations, 12 seeds, paired by seed — mean of the last 500 steps bf16 32.49 dB, fp32 32.55 dB, paired difference
+    -0.06 dB with standard error 0.07 (standard deviation of a single pair 0.25): within BASELINE.json's +-0.1 dB.  This
+    test is the one-seed, 1200-iteration version of that: the last-400-step means within 0.6 dB (> 2 sd of a pair), and
+    both paths above 24 dB."""
+    iters = 1200
     p32, t32 = train("fp32", iters)
     p16, t16 = train("bf16", iters)
-    tail32, tail16 = float(np.mean(p32[-100:])), float(np.mean(p16[-100:]))
-    print(f"train PSNR (last 100 of {iters}): fp32 {tail32:.2f} dB, bf16 {tail16:.2f} dB; "
+    tail32, tail16 = float(np.mean(p32[-400:])), float(np.mean(p16[-400:]))
+    print(f"train PSNR (last 400 of {iters}): fp32 {tail32:.2f} dB, bf16 {tail16:.2f} dB; "
           f"held-out view: fp32 {t32:.2f} dB, bf16 {t16:.2f} dB; start {np.mean(p32[:5]):.2f} dB")
     assert tail32 > 24.0, "fp32 path did not learn the scene"
     assert tail16 > 24.0, "bf16 path did not learn the scene"
-    assert abs(tail16 - tail32) < 0.7, (tail16, tail32)
+    assert abs(tail16 - tail32) < 0.6, (tail16, tail32)

@@ -90,3 +90,93 @@ def test_trainer_step_matches_oracle_train_step_for_three_steps():
         b = torch.cat([v.detach().double().reshape(-1) for v in p.values()]) - start.double()
         cos = float((a @ b) / (a.norm() * b.norm()))
         assert cos > 0.98, f"update direction: cosine {cos:.4f}"
+
+
+def _two_trainers(precision="fp32", Nf=128):
+    import spin_nerf_amd as S
+    train = importlib.import_module("spin-nerf_amd.train")
+    H, W, focal, near, far = 378, 504, 400.0, 1.2, 9.0
+    Nc, N = 64, 80
+    out = []
+    for _ in range(2):
+        nets = []
+        for seed in (0, 1):
+            n = S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True, precision=precision).cuda()
+            n.load_state_dict(O.init_nerf_params(seed=seed))
+            nets.append(n)
+
+        def q(inputs, viewdirs, network_fn):
+            return S.run_network(inputs, viewdirs, network_fn)
+        q._snr_fused = True
+        kw = dict(network_query_fn=q, perturb=1.0, N_importance=Nf, network_fine=nets[1] if Nf else None, N_samples=Nc,
+                  network_fn=nets[0], use_viewdirs=True, white_bkgd=True, raw_noise_std=1.0, ndc=False, lindisp=True,
+                  near=near, far=far)
+        out.append((train.RenderTrainer(kw, lrate=5e-4), nets))
+    g = torch.Generator().manual_seed(7)
+    ro, rd = O.get_rays(H, W, focal, torch.eye(4)[:3, :4])
+    sel = torch.randperm(H * W, generator=g)[:N]
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0).cuda()
+    target = torch.rand(N, 3, generator=g).cuda()
+    rnd = dict(t_rand=torch.rand(N, Nc, generator=g).cuda(), u=torch.rand(N, max(Nf, 1), generator=g).cuda() if Nf else None,
+               noise_c=torch.randn(N, Nc, generator=g).cuda(),
+               noise_f=torch.randn(N, Nc + Nf, generator=g).cuda() if Nf else None)
+    return out, (H, W, focal), rays, target, rnd
+
+
+@pytest.mark.parametrize("precision,Nf", [("fp32", 128), ("bf16", 128), ("fp32", 0)])
+def test_autograd_free_step_equals_the_autograd_step(monkeypatch, precision, Nf):
+    """RenderTrainer.step issues the launches of the plain configuration directly (compositing forward + loss + backward in
+    one kernel, no torch autograd); with the same injected draws it must give the loss, the render and the gradients of
+    the render() + autograd route, to rounding."""
+    (a, b), hwf, rays, target, rnd = _two_trainers(precision, Nf)
+    rnd = {k: v for k, v in rnd.items() if v is not None}
+    assert a[0]._direct_ok(rays, 32768, {"randoms": rnd})
+    la, rgb_a = a[0].step(*hwf, rays, target, randoms=rnd)
+    monkeypatch.setenv("SNR_NO_DIRECT_STEP", "1")
+    assert not b[0]._direct_ok(rays, 32768, {"randoms": rnd})
+    lb, rgb_b = b[0].step(*hwf, rays, target, randoms=rnd)
+    assert abs(float(la) - float(lb)) < 1e-6 * abs(float(lb))
+    assert float((rgb_a - rgb_b).abs().max()) < 1e-6
+    for na, nb in zip(a[1], b[1]):
+        if nb.flat.grad is None:
+            continue
+        rel = float((na.flat.grad - nb.flat.grad).norm() / nb.flat.grad.norm())
+        assert rel < 1e-5, rel
+        assert float((na.flat.detach() - nb.flat.detach()).abs().max()) < 2e-3   # (Adam: sign of rounding-level gradients)
+
+
+def test_in_kernel_random_draws():
+    """The production draws (Philox4x32-10 in-kernel, tests/helpers.py restates the generator; its known answers are
+    pinned in tests/test_oracle_golden.py): the stratified offsets ARE that stream, the density noise is N(0, std) and is
+    the same in the forward and the backward half, and two calls with different offsets are independent."""
+    import spin_nerf_amd as S
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import philox_uniform
+    ops = S.ops
+    n, N = 300, 64
+    rays = torch.zeros(n, 11); rays[:, 6] = 1.2; rays[:, 7] = 9.0; rays[:, 5] = -1.0; rays[:, 10] = -1.0
+    seed, off = 0x123456789ABCDEF, 5
+    z = ops.sample_coarse_rng(rays.cuda(), N, True, seed, off)
+    u, _ = philox_uniform(n * N, seed, off)
+    z_ref = ops.sample_coarse(rays.cuda(), N, True, torch.from_numpy(u).reshape(n, N).cuda())
+    assert torch.equal(z, z_ref)
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.01
+    # density noise through the compositing kernel: raw = 0, two samples one unit apart on a unit direction ->
+    # weights[:, 0] = 1 - exp(-relu(noise_0)): recover the positive half of the draws
+    nr = 20000
+    r2 = torch.zeros(nr, 11); r2[:, 5] = -1.0
+    zz = torch.tensor([[0.0, 1.0]]).repeat(nr, 1)
+    raw = torch.zeros(nr, 2, 4)
+    loss = torch.zeros(2, device="cuda")
+    tgt = torch.zeros(nr, 3)
+    outs = [ops.composite_train(raw.cuda(), zz.cuda(), r2.cuda(), tgt.cuda(), loss[0:1], None, noise_std=2.0, seed=seed, offset=o)
+            for o in (9, 9, 10)]
+    w0 = outs[0][4][:, 0].double().cpu()
+    noise_pos = -torch.log1p(-w0[w0 > 0].clamp(max=1 - 1e-7)) / 1.0
+    frac = float((w0 > 0).double().mean())
+    assert abs(frac - 0.5) < 0.02, frac
+    assert abs(float(noise_pos.mean()) - 2.0 * 0.7979) < 0.06 and abs(float((noise_pos ** 2).mean()) - 4.0) < 0.25
+    assert torch.equal(outs[0][4], outs[1][4]) and torch.equal(outs[0][5], outs[1][5])      # same (seed, offset): same draws
+    assert float((outs[0][4][:, 0] != outs[2][4][:, 0]).float().mean()) > 0.4               # next offset: new draws
+    assert bool(torch.isfinite(outs[0][5]).all())

@@ -177,3 +177,16 @@ def test_inverse_cdf_resampling_is_ill_conditioned_in_the_reference_arithmetic_i
         assert float(moved.any(-1).double().mean()) > 0.1
         # the coarse stage has no resampling upstream and agrees tightly
         assert float((a[4]["rgb0"].double() - b[4]["rgb0"]).abs().max()) < 1e-4   # (measured 2e-5 on these wild networks)
+
+
+def test_philox_restatement_against_the_published_known_answers():
+    """Random123's known-answer vectors for philox4x32-10 pin the numpy restatement the GPU tests compare the kernels'
+    draws with."""
+    from helpers import philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = philox4x32_10(np.array(ctr, dtype=np.uint32), key)
+        assert tuple(int(x) for x in got) == want, (ctr, [hex(int(x)) for x in got])
