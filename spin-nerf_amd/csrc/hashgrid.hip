@@ -414,7 +414,12 @@ __global__ __launch_bounds__(64 * kHgWaves) void hg_bwd_kernel(HgTable T, const 
           const uint32_t k_lo = (uint32_t)(int)fx | ((uint32_t)(int)fy << 21);
           const uint32_t k_hi = ((uint32_t)(int)fy >> 11) | ((uint32_t)(int)fz << 10);
           bool active = valid;
-          for (int it = 0; it < kMerge; ++it) {
+          // consecutive samples of a ray are neighbouring lanes: when no lane shares its cell with the lane before it
+          // (the fine levels), there is nothing to merge and the leader rounds would be wasted
+          const bool dup = k_lo == (uint32_t)__shfl_up((int)k_lo, 1, 64) && k_hi == (uint32_t)__shfl_up((int)k_hi, 1, 64) &&
+                           (lane & 31) != 0;
+          const int rounds = __ballot(dup && valid) ? kMerge : 0;
+          for (int it = 0; it < rounds; ++it) {
             const unsigned long long bal = __ballot(active);
             if (bal == 0) break;                                   // wave-uniform
             const uint32_t half = g ? (uint32_t)(bal >> 32) : (uint32_t)bal;
