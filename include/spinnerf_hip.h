@@ -135,6 +135,17 @@ int snr_composite_backward(const float* raw, int raw_ch, const float* z_vals, co
                            const float* g_rgb, const float* g_disp, const float* g_acc, const float* g_depth,
                            const float* g_weights, const float* g_alpha, float* d_raw, snr_stream_t stream);
 
+/* Compositing from opacities the caller computed: MVSeg's raw2outputs post-processes alpha before the transmittance
+ * product when only_object is set (MVSeg/DS_NeRF/run_nerf_helpers.py:383-397).  alpha [n_rays,S]; colours from
+ * raw[..., :3].  Backward: d_raw gets the colour gradients (channels >= 3 are 0), d_alpha [n_rays,S] = d loss / d alpha. */
+int snr_composite_alpha_forward(const float* raw, int raw_ch, const float* z_vals, const float* rays, int ray_ld,
+                                const float* alpha, int64_t n_rays, int S, int white_bkgd, float* rgb_map,
+                                float* disp_map, float* acc_map, float* depth_map, float* weights, snr_stream_t stream);
+int snr_composite_alpha_backward(const float* raw, int raw_ch, const float* z_vals, const float* rays, int ray_ld,
+                                 const float* alpha, int64_t n_rays, int S, int white_bkgd, int detach_weights,
+                                 const float* g_rgb, const float* g_disp, const float* g_acc, const float* g_depth,
+                                 const float* g_weights, float* d_raw, float* d_alpha, snr_stream_t stream);
+
 /* ---- hierarchical sampling: replaces sample_pdf + sort + z_std
  * (helpers:304-347, run_nerf.py:697-702, 726) ----
  * bins = midpoints of z_coarse, pdf from weights[:,1:-1]; u [n_rays, n_fine] or NULL (= the

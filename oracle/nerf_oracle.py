@@ -317,13 +317,38 @@ def raw2outputs(raw, z_vals, rays_d, noise=None, white_bkgd=False, need_alpha=Fa
 # the reference's pytest=True random hook
 # --------------------------------------------------------------------------
 
-def raw2outputs_mvseg(raw, z_vals, rays_d, noise=None, white_bkgd=False):
-    """MVSeg variant (MVSeg/DS_NeRF/run_nerf_helpers.py:350-413, default path: no only_object): raw carries a 5th
-    channel of per-sample logits, composited with DETACHED weights: prob_map = sum(w.detach() * logit) (:405).
+def raw2outputs_mvseg(raw, z_vals, rays_d, noise=None, white_bkgd=False, only_object=False, threshold=None,
+                      harsh_bg_remove=False):
+    """MVSeg variant (MVSeg/DS_NeRF/run_nerf_helpers.py:350-413): raw carries a 5th channel of per-sample logits,
+    composited with DETACHED weights: prob_map = sum(w.detach() * logit) (:405).  `only_object` (:383-397): alpha is
+    multiplied by 1 - sigmoid(logit), with `threshold` zeroed above it and box-smoothed five times along the ray;
+    `harsh_bg_remove` (:410-411) subtracts 10 (1 - acc) from prob_map.
     Returns (rgb_map, disp_map, acc_map, weights, depth_map, prob_map, logits)."""
-    rgb_map, disp_map, acc_map, weights, depth_map, _ = raw2outputs(raw, z_vals, rays_d, noise, white_bkgd)
     logits = raw[..., 4]
+    if not only_object:
+        rgb_map, disp_map, acc_map, weights, depth_map, _ = raw2outputs(raw, z_vals, rays_d, noise, white_bkgd)
+    else:
+        dists = z_vals[..., 1:] - z_vals[..., :-1]
+        dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1)
+        dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
+        sig = raw[..., 3] if noise is None else raw[..., 3] + noise
+        alpha = (1. - torch.exp(-F.relu(sig) * dists)) * (1 - torch.sigmoid(logits))
+        if threshold is not None:
+            alpha = torch.where(alpha > threshold, torch.zeros_like(alpha), alpha)     # alpha[alpha > threshold] = 0
+            for _ in range(5):
+                z0 = torch.zeros((alpha.shape[0], 1), dtype=alpha.dtype)
+                alpha = (torch.hstack([z0, alpha[:, :-1]]) + alpha + torch.hstack([alpha[:, 1:], z0])) / 3
+        T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1. - alpha + 1e-10], -1), -1)[:, :-1]
+        weights = alpha * T
+        rgb_map = torch.sum(weights[..., None] * torch.sigmoid(raw[..., :3]), -2)
+        depth_map = torch.sum(weights * z_vals, -1)
+        acc_map = torch.sum(weights, -1)
+        disp_map = 1. / torch.max(1e-10 * torch.ones_like(depth_map), depth_map / acc_map)
+        if white_bkgd:
+            rgb_map = rgb_map + (1. - acc_map[..., None])
     prob_map = torch.sum(weights.detach() * logits, -1)
+    if only_object and harsh_bg_remove:
+        prob_map = prob_map - 10 * (1. - acc_map)
     return rgb_map, disp_map, acc_map, weights, depth_map, prob_map, logits
 
 

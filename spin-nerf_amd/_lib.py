@@ -53,6 +53,8 @@ SIGNATURES = {
     "snr_sample_coarse": (_i, [_p, _i, _l, _i, _i, _p, _p, _p]),
     "snr_composite_forward": (_i, [_p, _i, _p, _p, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "snr_composite_backward": (_i, [_p, _i, _p, _p, _i, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "snr_composite_alpha_forward": (_i, [_p, _i, _p, _p, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "snr_composite_alpha_backward": (_i, [_p, _i, _p, _p, _i, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "snr_sample_fine": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p, _p]),
     "snr_sample_coarse_rng": (_i, [_p, _i, _l, _i, _i, _c.c_uint64, _c.c_uint64, _p, _p]),
     "snr_sample_fine_rng": (_i, [_p, _p, _l, _i, _i, _c.c_uint64, _c.c_uint64, _p, _p, _p, _p]),

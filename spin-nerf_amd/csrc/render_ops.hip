@@ -126,7 +126,8 @@ struct CompMaps { float r, g, b, disp, acc, depth; };   // the same values in ev
 // forward of one ray by one wave: weights (and alpha) to memory, the maps returned
 __device__ __forceinline__ CompMaps composite_fwd_ray(const float* __restrict__ raw, int C, const float* __restrict__ zr,
                                                       float dn, const NoiseSrc& ns, int64_t ray, int S, int white, int lane,
-                                                      float* __restrict__ weights, float* __restrict__ alpha_out) {
+                                                      float* __restrict__ weights, float* __restrict__ alpha_out,
+                                                      const float* __restrict__ alpha_in = nullptr) {
   float T = 1.f;  // transmittance entering this chunk
   float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
   for (int base = 0; base < S; base += kWave) {
@@ -140,7 +141,8 @@ __device__ __forceinline__ CompMaps composite_fwd_ray(const float* __restrict__ 
       const float* rw = raw + (ray * S + i) * C;
       c0 = sigmoidf(rw[0]); c1 = sigmoidf(rw[1]); c2 = sigmoidf(rw[2]);
       const float s = rw[3] + noise_at(ns, ray * S + i);
-      const float a = 1.f - expf(-fmaxf(s, 0.f) * dist);  // helpers:364,382
+      // alpha_in: the caller's own opacities (MVSeg's only_object post-processing) instead of helpers:364,382
+      const float a = alpha_in ? alpha_in[ray * S + i] : 1.f - expf(-fmaxf(s, 0.f) * dist);
       if (alpha_out) alpha_out[ray * S + i] = a;
       one_m = 1.f - a + 1e-10f;
       w = a;
@@ -165,13 +167,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
     NoiseSrc ns, int64_t n_rays, int S, int white, float* __restrict__ rgb_map,
     float* __restrict__ disp_map, float* __restrict__ acc_map, float* __restrict__ depth_map,
-    float* __restrict__ weights, float* __restrict__ alpha_out) {
+    float* __restrict__ weights, float* __restrict__ alpha_out, const float* __restrict__ alpha_in) {
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
   const float* rd = rays + ray * ld + 3;
   const float dn = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);  // torch.norm
-  const CompMaps m = composite_fwd_ray(raw, C, z_vals + ray * S, dn, ns, ray, S, white, lane, weights, alpha_out);
+  const CompMaps m = composite_fwd_ray(raw, C, z_vals + ray * S, dn, ns, ray, S, white, lane, weights, alpha_out, alpha_in);
   if (lane == 0) {
     rgb_map[3 * ray] = m.r; rgb_map[3 * ray + 1] = m.g; rgb_map[3 * ray + 2] = m.b;
     disp_map[ray] = m.disp; acc_map[ray] = m.acc; depth_map[ray] = m.depth;
@@ -184,7 +186,9 @@ __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ raw,
                                                   float dn, const NoiseSrc& ns, int64_t ray, int S, int white, int detach,
                                                   float gr, float gg, float gb, float gD, float gA, float gP,
                                                   const float* __restrict__ g_w, const float* __restrict__ g_alpha,
-                                                  float* __restrict__ d_raw, int lane) {
+                                                  float* __restrict__ d_raw, int lane,
+                                                  const float* __restrict__ alpha_in = nullptr,
+                                                  float* __restrict__ d_alpha_out = nullptr) {
   const int nchunks = (S + kWave - 1) / kWave;
   // pass 1: recompute w, accumulate acc/depth (needed for the disparity term)
   float T = 1.f, sd = 0.f, sa = 0.f;
@@ -195,7 +199,7 @@ __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ raw,
       z = zr[i];
       const float dist = ((i + 1 < S) ? (zr[i + 1] - z) : 1e10f) * dn;
       const float s = raw[(ray * S + i) * C + 3] + noise_at(ns, ray * S + i);
-      a = 1.f - expf(-fmaxf(s, 0.f) * dist);
+      a = alpha_in ? alpha_in[ray * S + i] : 1.f - expf(-fmaxf(s, 0.f) * dist);
       one_m = 1.f - a + 1e-10f;
     }
     const float incl = wave_incl_scan_mul(one_m, lane);
@@ -222,7 +226,7 @@ __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ raw,
       const float z2 = zr[i2];
       const float dist2 = ((i2 + 1 < S) ? (zr[i2 + 1] - z2) : 1e10f) * dn;
       const float s2 = raw[(ray * S + i2) * C + 3] + noise_at(ns, ray * S + i2);
-      const float a2 = 1.f - expf(-fmaxf(s2, 0.f) * dist2);
+      const float a2 = alpha_in ? alpha_in[ray * S + i2] : 1.f - expf(-fmaxf(s2, 0.f) * dist2);
       const float incl2 = wave_incl_scan_mul(1.f - a2 + 1e-10f, lane);
       Tin = Tin * __shfl(incl2, kWave - 1, kWave);
     }
@@ -235,7 +239,7 @@ __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ raw,
       const float* rw = raw + (ray * S + i) * C;
       r0 = rw[0]; r1 = rw[1]; r2 = rw[2];
       s = rw[3] + noise_at(ns, ray * S + i);
-      a = 1.f - expf(-fmaxf(s, 0.f) * dist);
+      a = alpha_in ? alpha_in[ray * S + i] : 1.f - expf(-fmaxf(s, 0.f) * dist);
       one_m = 1.f - a + 1e-10f;
     }
     const float incl = wave_incl_scan_mul(one_m, lane);
@@ -255,8 +259,9 @@ __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ raw,
     if (in) {
       float dalpha = G * Ti - suf_excl / one_m;
       if (g_alpha) dalpha += g_alpha[ray * S + i];
-      // d alpha / d s = dist * exp(-relu(s) dist) for s > 0
-      const float ds = (s > 0.f) ? dalpha * dist * expf(-s * dist) : 0.f;
+      // d alpha / d s = dist * exp(-relu(s) dist) for s > 0; with the caller's own opacities the gradient stops at alpha
+      const float ds = alpha_in ? 0.f : ((s > 0.f) ? dalpha * dist * expf(-s * dist) : 0.f);
+      if (d_alpha_out) d_alpha_out[ray * S + i] = dalpha;
       float* o = d_raw + (ray * S + i) * C;
       o[0] = gr * w * c0 * (1.f - c0);
       o[1] = gg * w * c1 * (1.f - c1);
@@ -271,7 +276,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
     NoiseSrc ns, int64_t n_rays, int S, int white, int detach, const float* __restrict__ g_rgb,
     const float* __restrict__ g_disp, const float* __restrict__ g_acc, const float* __restrict__ g_depth,
-    const float* __restrict__ g_w, const float* __restrict__ g_alpha, float* __restrict__ d_raw) {
+    const float* __restrict__ g_w, const float* __restrict__ g_alpha, float* __restrict__ d_raw,
+    const float* __restrict__ alpha_in, float* __restrict__ d_alpha_out) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
   if (ray >= n_rays) return;
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
               gb = g_rgb ? g_rgb[3 * ray + 2] : 0.f;
   const float gD = g_depth ? g_depth[ray] : 0.f, gA = g_acc ? g_acc[ray] : 0.f, gP = g_disp ? g_disp[ray] : 0.f;
   composite_bwd_ray(raw, C, z_vals + ray * S, dn, ns, ray, S, white, detach, gr, gg, gb, gD, gA, gP, g_w, g_alpha, d_raw,
-                    lane);
+                    lane, alpha_in, d_alpha_out);
 }
 
 // One kernel per network of the TRAINING step: compositing forward, the loss term mean((rgb - target)^2) of this
@@ -599,7 +605,7 @@ extern "C" int snr_composite_forward(const float* raw, int C, const float* z, co
     ProfScope ps(K_COMPOSITE_FWD, (hipStream_t)stream);
     composite_fwd_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(raw, C, z, rays, ld, NoiseSrc{noise, 0, Rng{}, 0.f},
                                                                             n_rays, S, white, rgb_map, disp_map, acc_map,
-                                                                            depth_map, weights, alpha);
+                                                                            depth_map, weights, alpha, nullptr);
   }
   return launch_status();
 }
@@ -616,7 +622,7 @@ extern "C" int snr_composite_backward(const float* raw, int C, const float* z, c
     ProfScope ps(K_COMPOSITE_BWD, (hipStream_t)stream);
     composite_bwd_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(
         raw, C, z, rays, ld, NoiseSrc{noise, 0, Rng{}, 0.f}, n_rays, S, white, detach, g_rgb, g_disp, g_acc, g_depth, g_w,
-        g_alpha, d_raw);
+        g_alpha, d_raw, nullptr, nullptr);
   }
   return launch_status();
 }
@@ -662,6 +668,42 @@ extern "C" int snr_sample_pdf(const float* bins, const float* weights, const flo
     ProfScope ps(K_SAMPLE_FINE, (hipStream_t)stream);
     sample_fine_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(bins, weights, u, n_rays, Nc, n_samples, npow2,
                                                                             nullptr, samples, nullptr, 1, 0, Rng{});
+  }
+  return launch_status();
+}
+
+// Compositing from opacities the caller computed (MVSeg's only_object path post-processes alpha before the
+// transmittance product, MVSeg/DS_NeRF/run_nerf_helpers.py:383-397): colours from raw[..., :3], alpha [n_rays,S] as given.
+extern "C" int snr_composite_alpha_forward(const float* raw, int C, const float* z, const float* rays, int ld,
+                                           const float* alpha, int64_t n_rays, int S, int white, float* rgb_map,
+                                           float* disp_map, float* acc_map, float* depth_map, float* weights,
+                                           snr_stream_t stream) {
+  SNR_CHECK_ARG(raw && z && rays && alpha && rgb_map && disp_map && acc_map && depth_map && weights, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_rays > 0 && S > 0 && C >= 4 && ld >= 6, SNR_ERR_SHAPE);
+  const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  {
+    ProfScope ps(K_COMPOSITE_FWD, (hipStream_t)stream);
+    composite_fwd_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(raw, C, z, rays, ld, NoiseSrc{nullptr, 0, Rng{}, 0.f},
+                                                                            n_rays, S, white, rgb_map, disp_map, acc_map,
+                                                                            depth_map, weights, nullptr, alpha);
+  }
+  return launch_status();
+}
+
+/* d_raw [n_rays,S,C]: colour channels only (channel 3 and up get 0); d_alpha [n_rays,S] = d loss / d alpha */
+extern "C" int snr_composite_alpha_backward(const float* raw, int C, const float* z, const float* rays, int ld,
+                                            const float* alpha, int64_t n_rays, int S, int white, int detach,
+                                            const float* g_rgb, const float* g_disp, const float* g_acc,
+                                            const float* g_depth, const float* g_w, float* d_raw, float* d_alpha,
+                                            snr_stream_t stream) {
+  SNR_CHECK_ARG(raw && z && rays && alpha && d_raw && d_alpha, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_rays > 0 && S > 0 && C >= 4 && ld >= 6, SNR_ERR_SHAPE);
+  const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  {
+    ProfScope ps(K_COMPOSITE_BWD, (hipStream_t)stream);
+    composite_bwd_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(
+        raw, C, z, rays, ld, NoiseSrc{nullptr, 0, Rng{}, 0.f}, n_rays, S, white, detach, g_rgb, g_disp, g_acc, g_depth, g_w,
+        nullptr, d_raw, alpha, d_alpha);
   }
   return launch_status();
 }

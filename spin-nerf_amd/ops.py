@@ -130,18 +130,78 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=F
     return rgb, disp, acc, w, depth, alpha
 
 
-def raw2outputs_mvseg(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, noise=None, rays=None):
-    """MVSeg's 5-channel variant (MVSeg/DS_NeRF/run_nerf_helpers.py:350-413, default path — `only_object` and its
-    alpha post-processing are not built): the compositing kernel handles channels 0..3 and
-    zeroes the gradient of channel 4; the logit channel is composited with the DETACHED weights
-    (`prob_map = sum(w.detach() * logit)`, :405), so its gradient reaches raw[..., 4] only.
+class _CompositeAlpha(torch.autograd.Function):
+    """compositing from caller-computed opacities (snr_composite_alpha_forward / _backward)"""
+
+    @staticmethod
+    def forward(ctx, raw, alpha, z_vals, rays, white_bkgd):
+        lib = _lib.load()
+        raw_c, a, z, r = f32c(raw), f32c(alpha), f32c(z_vals), f32c(rays)
+        n, S, C = raw_c.shape
+        dev = raw_c.device
+        rgb = torch.empty(n, 3, device=dev); disp = torch.empty(n, device=dev); acc = torch.empty(n, device=dev)
+        depth = torch.empty(n, device=dev); w = torch.empty(n, S, device=dev)
+        check(lib.snr_composite_alpha_forward(ptr(raw_c), C, ptr(z), ptr(r), r.shape[1], ptr(a), n, S, int(bool(white_bkgd)),
+                                              ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(w), stream()),
+              "snr_composite_alpha_forward")
+        ctx.save_for_backward(raw_c, a, z, r)
+        ctx.white = int(bool(white_bkgd))
+        ctx.set_materialize_grads(False)
+        return rgb, disp, acc, depth, w
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_w):
+        lib = _lib.load()
+        raw, a, z, r = ctx.saved_tensors
+        n, S, C = raw.shape
+        d_raw, d_alpha = torch.empty_like(raw), torch.empty_like(a)
+        gs = [f32c(g) if g is not None else None for g in (g_rgb, g_disp, g_acc, g_depth, g_w)]
+        check(lib.snr_composite_alpha_backward(ptr(raw), C, ptr(z), ptr(r), r.shape[1], ptr(a), n, S, ctx.white, 0, ptr(gs[0]),
+                                               ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]), ptr(d_raw), ptr(d_alpha),
+                                               stream()), "snr_composite_alpha_backward")
+        return d_raw, d_alpha, None, None, None
+
+
+def raw2outputs_mvseg(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, only_object=False,
+                      threshold=None, harsh_bg_remove=False, noise=None, rays=None):
+    """MVSeg's 5-channel raw2outputs with its signature (MVSeg/DS_NeRF/run_nerf_helpers.py:350-413): the logit channel
+    is composited with the DETACHED weights (`prob_map = sum(w.detach() * logit)`, :405).
+
+    Default path: the compositing kernel handles channels 0..3 and zeroes the gradient of channel 4.
+    ``only_object`` (:383-397, 410-411): the opacity is multiplied by 1 - sigmoid(logit), optionally zeroed above
+    ``threshold`` and box-smoothed 5 times along the ray, BEFORE the transmittance product — those few element-wise steps
+    on [N_rays, S] are torch ops feeding the kernel's composite-from-alpha entry point (MVSeg's evaluation path, not the
+    training hot path); ``harsh_bg_remove`` subtracts 10 (1 - acc) from prob_map.
     Returns (rgb_map, disp_map, acc_map, weights, depth_map, prob_map, logits)."""
+    import numpy as np
     if raw.shape[-1] < 5:
         raise ValueError("raw2outputs_mvseg needs 5 raw channels (rgb, sigma, logit)")
-    rgb, disp, acc, w, depth, _ = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd, pytest, noise=noise,
-                                              rays=rays)
     logits = raw[..., 4]
+    if not only_object:
+        rgb, disp, acc, w, depth, _ = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd, pytest, noise=noise,
+                                                  rays=rays)
+    else:
+        if noise is None and raw_noise_std > 0.:
+            if pytest:
+                np.random.seed(0)
+                noise = torch.Tensor(np.random.rand(*list(raw[..., 3].shape)) * raw_noise_std).to(raw.device)
+            else:
+                noise = torch.randn(raw[..., 3].shape, device=raw.device) * raw_noise_std
+        dists = z_vals[..., 1:] - z_vals[..., :-1]
+        dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1) * torch.norm(rays_d[..., None, :], dim=-1)
+        sig = raw[..., 3] if noise is None else raw[..., 3] + noise
+        alpha = (1. - torch.exp(-torch.relu(sig) * dists)) * (1 - torch.sigmoid(logits))
+        if threshold is not None:
+            alpha = torch.where(alpha > threshold, torch.zeros_like(alpha), alpha)
+            zero = torch.zeros_like(alpha[:, :1])
+            for _ in range(5):
+                alpha = (torch.cat([zero, alpha[:, :-1]], 1) + alpha + torch.cat([alpha[:, 1:], zero], 1)) / 3
+        if rays is None:
+            rays = torch.cat([torch.zeros_like(rays_d), rays_d], -1)
+        rgb, disp, acc, depth, w = _CompositeAlpha.apply(raw, alpha, z_vals, rays, white_bkgd)
     prob = torch.sum(w.detach() * logits, -1)
+    if only_object and harsh_bg_remove:
+        prob = prob - 10 * (1. - acc)
     return rgb, disp, acc, w, depth, prob, logits
 
 

@@ -5,6 +5,8 @@ spiral render path, the hold-out view — and the ray table `train()` builds fro
 
 Pinned by fixtures produced by the reference's own `load_llff_data` with only its file reader replaced by synthetic
 arrays (tests/golden/make_golden_poses.py)."""
+import os
+
 import numpy as np
 
 
@@ -270,3 +272,201 @@ def load_llff_data(basedir, factor=8, recenter=True, bd_factor=.75, spherify=Fal
     depths = np.moveaxis(depths, -1, 0).astype(np.float32)
     poses, bds, render_poses, i_test = llff_poses(poses, bds, recenter, bd_factor, spherify, path_zflat, spherify_hack)
     return images, poses, bds, render_poses, i_test, masks, depths, mask_indices
+
+
+# ----------------------------------------------------------------------------------------------
+# COLMAP sparse depth (load_llff.py:436-501) and pre-scaled image folders (load_llff.py:14-66)
+# ----------------------------------------------------------------------------------------------
+def read_images_binary(path):
+    """COLMAP images.bin -> {image_id: dict(qvec, tvec, camera_id, name, xys [n,2], point3D_ids [n])}
+    (format of colmapUtils/read_write_model.py:225-257: uint64 count; per image int32 id, 4+3 doubles, int32 camera, a
+    zero-terminated name, uint64 n, n x (double x, double y, int64 point3D id))"""
+    import struct
+    out = {}
+    with open(path, "rb") as f:
+        n_img = struct.unpack("<Q", f.read(8))[0]
+        for _ in range(n_img):
+            vals = struct.unpack("<idddddddi", f.read(64))
+            name = b""
+            while True:
+                c = f.read(1)
+                if c == b"\x00":
+                    break
+                name += c
+            n2d = struct.unpack("<Q", f.read(8))[0]
+            rec = np.frombuffer(f.read(24 * n2d), dtype=np.dtype([("x", "<f8"), ("y", "<f8"), ("id", "<i8")]))
+            out[vals[0]] = dict(qvec=np.array(vals[1:5]), tvec=np.array(vals[5:8]), camera_id=vals[8],
+                                name=name.decode("utf-8"), xys=np.column_stack([rec["x"], rec["y"]]).reshape(-1, 2),
+                                point3D_ids=rec["id"].astype(np.int64))
+    return out
+
+
+def read_points3d_binary(path):
+    """COLMAP points3D.bin -> {point3D_id: dict(xyz, rgb, error)} (read_write_model.py:336-363; tracks are skipped)"""
+    import struct
+    out = {}
+    with open(path, "rb") as f:
+        n = struct.unpack("<Q", f.read(8))[0]
+        for _ in range(n):
+            vals = struct.unpack("<QdddBBBd", f.read(43))
+            track = struct.unpack("<Q", f.read(8))[0]
+            f.seek(8 * track, 1)
+            out[vals[0]] = dict(xyz=np.array(vals[1:4]), rgb=np.array(vals[4:7]), error=float(vals[7]))
+    return out
+
+
+def qvec2rotmat(q):
+    """read_write_model.py: Image.qvec2rotmat (w, x, y, z)"""
+    w, x, y, z = q
+    return np.array([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * z * x + 2 * w * y],
+                     [2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * x],
+                     [2 * z * x - 2 * w * y, 2 * y * z + 2 * w * x, 1 - 2 * x * x - 2 * y * y]])
+
+
+def colmap_poses(images):
+    """camera-to-world matrices in image-id order of the dict (load_llff.py:436-445)"""
+    poses = []
+    for i in images:
+        w2c = np.concatenate([np.concatenate([qvec2rotmat(images[i]["qvec"]), images[i]["tvec"].reshape(3, 1)], 1),
+                              np.array([[0, 0, 0, 1.]])], 0)
+        poses.append(np.linalg.inv(w2c))
+    return np.array(poses)
+
+
+def load_colmap_depth(basedir, factor=8, bd_factor=.75, prepare=False, bds_raw=None, save=True):
+    """Per-image sparse depths from the COLMAP reconstruction (load_llff.py:448-501): for every registered 2D point
+    with a 3D point, depth = camera z-axis . (X - camera position) * sc, kept when inside the image's [near, far] bounds,
+    with weight 2 exp(-(err / mean err)^2) and pixel coordinates / factor.  Returns (and saves to colmap_depth.npy like the
+    reference) a list of dicts {"depth", "coord", "weight"}; ``bds_raw`` [N,2] overrides the bounds read from
+    poses_bounds.npy (the reference takes them from _load_data)."""
+    images = read_images_binary(os.path.join(basedir, "sparse", "0", "images.bin"))
+    points = read_points3d_binary(os.path.join(basedir, "sparse", "0", "points3D.bin"))
+    err_mean = np.mean(np.array([p["error"] for p in points.values()]))
+    print("Mean Projection Error:", err_mean)
+    poses = colmap_poses(images)
+    if bds_raw is None:
+        arr = np.load(os.path.join(basedir, "poses_bounds.npy"))
+        bds_raw = arr[:, -2:]
+    bds_raw = np.asarray(bds_raw).astype(np.float32)
+    sc = 1. if bd_factor is None else 1. / (bds_raw.min() * bd_factor)
+    print('near/far:', np.ndarray.min(bds_raw) * .9 * sc, np.ndarray.max(bds_raw) * 1. * sc)
+    data_list = []
+    for id_im in range(1, len(images) + 1):
+        depth_list, coord_list, weight_list = [], [], []
+        im = images[id_im]
+        for i in range(len(im["xys"])):
+            id_3d = im["point3D_ids"][i]
+            if id_3d == -1:
+                continue
+            p3 = points[id_3d]
+            depth = (poses[id_im - 1, :3, 2].T @ (p3["xyz"] - poses[id_im - 1, :3, 3])) * sc
+            if depth < bds_raw[id_im - 1, 0] * sc or depth > bds_raw[id_im - 1, 1] * sc:
+                continue
+            depth_list.append(depth)
+            coord_list.append(im["xys"][i] / factor)
+            weight_list.append(2 * np.exp(-(p3["error"] / err_mean) ** 2))
+        if len(depth_list) > 0:
+            data_list.append({"depth": np.array(depth_list), "coord": np.array(coord_list), "weight": np.array(weight_list)})
+    if save:
+        np.save(os.path.join(basedir, "colmap_depth.npy"), np.array(data_list, dtype=object), allow_pickle=True)
+    return data_list
+
+
+def minify(basedir, factors=(), resolutions=()):
+    """Pre-scaled copies of <basedir>/images as images_<f> / images_<W>x<H> PNG folders (load_llff.py:14-66).  The reference
+    shells out to ImageMagick's `mogrify -resize`; neither it nor cv2 is on this image, so the resampling is PIL's (box
+    reduction for integer factors, LANCZOS otherwise) — parity unpinned, the folder / naming contract is the reference's."""
+    from PIL import Image
+    imgdir = os.path.join(basedir, "images")
+    names = [f for f in sorted(os.listdir(imgdir)) if f.split(".")[-1] in ("JPG", "jpg", "png", "jpeg", "PNG")]
+    for r in list(factors) + list(resolutions):
+        name = "images_{}".format(r) if isinstance(r, int) else "images_{}x{}".format(r[1], r[0])
+        out = os.path.join(basedir, name)
+        if os.path.exists(out):
+            continue
+        print("Minifying", r, basedir)
+        os.makedirs(out)
+        for f in names:
+            im = Image.open(os.path.join(imgdir, f))
+            if isinstance(r, int):
+                size = (int(round(im.size[0] / r)), int(round(im.size[1] / r)))
+                small = im.reduce(r) if (im.size[0] % r == 0 and im.size[1] % r == 0) else im.resize(size, Image.LANCZOS)
+            else:
+                small = im.resize((r[1], r[0]), Image.LANCZOS)
+            small.save(os.path.join(out, f.rsplit(".", 1)[0] + ".png"))
+
+
+# ----------------------------------------------------------------------------------------------
+# train()'s ray tables and its four shuffled feeds (run_nerf.py:1228-1348, 1362-1417)
+# ----------------------------------------------------------------------------------------------
+def build_depth_rays(depth_gts, masks, poses, H, W, focal, i_train, prepare=False):
+    """rays_depth [n, 4, 3] = (ray origin, ray direction, depth x3, weight x3) of the COLMAP points of the training views
+    that fall outside the object mask (run_nerf.py:1264-1300), and max_depth = max weight-column value as the
+    reference computes it (:1302-1303 takes column 3)."""
+    out = []
+    for i in i_train:
+        g = depth_gts[i]
+        coord, weight, depth = g["coord"], g["weight"], g["depth"]
+        if not prepare:
+            keep = [k for k in range(len(coord))
+                    if masks[i][min(int(coord[k][1]), masks[i].shape[0] - 1)][min(int(coord[k][0]), masks[i].shape[1] - 1)] == 0]
+            coord, weight, depth = coord[keep], weight[keep], depth[keep]
+        rays = np.stack(get_rays_by_coord_np(H, W, focal, poses[i, :3, :4], coord), axis=0)      # 2 x n x 3
+        rays = np.transpose(rays, [1, 0, 2])
+        dv = np.repeat(depth[:, None, None], 3, axis=2)
+        wv = np.repeat(weight[:, None, None], 3, axis=2)
+        out.append(np.concatenate([rays, dv, wv], axis=1))
+    rays_depth = np.concatenate(out, axis=0).astype(np.float32)
+    return rays_depth, float(np.max(rays_depth[:, 3, 0]))
+
+
+def split_ray_tables(rays_rgb, rays_inp, prepare=False, train_gt=False):
+    """The three tables train() samples from (run_nerf.py:1306-1322): rows are [3, 4] = (o | d | rgb) x (xyz, label).
+    -> (rays_rgb: pixels of label 1 unless --prepare, rays_rgb_clf: label 0 unless --train_gt / --prepare,
+        rays_inp: the inpainted-depth table at the pixels whose label is not 0)"""
+    lab = rays_rgb[:, :, 3]
+    clf = rays_rgb.reshape(-1, 3, 4) if (train_gt or prepare) else rays_rgb[lab == 0].reshape(-1, 3, 4)
+    inp = rays_inp[lab != 0].reshape(-1, 3, 4)
+    rgb = rays_rgb if prepare else rays_rgb[lab == 1].reshape(-1, 3, 4)
+    return rgb, clf, inp
+
+
+class RayFeeds:
+    """The shuffled mini-batch feeds of train() (run_nerf.py:1336-1348, 1362-1417): one per table, each a pass over a
+    fresh random permutation of its rows in batches of N_rand (the last batch of a pass is short, like DataLoader's),
+    restarted when exhausted.  Tables live on the device; a batch is one index_select."""
+
+    def __init__(self, rays_rgb, rays_inp, rays_rgb_clf, rays_depth=None, N_rand=1024, device="cuda", seed=None):
+        import torch
+        self.torch = torch
+        self.N = N_rand
+        self.gen = torch.Generator(device="cpu")
+        if seed is not None:
+            self.gen.manual_seed(seed)
+        self.tab = {k: torch.as_tensor(v, dtype=torch.float32).to(device) for k, v in
+                    (("rgb", rays_rgb), ("inp", rays_inp), ("clf", rays_rgb_clf), ("depth", rays_depth)) if v is not None}
+        self.perm, self.pos = {}, {}
+
+    def _next(self, key):
+        t = self.tab[key]
+        if key not in self.perm or self.pos[key] >= t.shape[0]:
+            self.perm[key] = self.torch.randperm(t.shape[0], generator=self.gen).to(t.device)
+            self.pos[key] = 0
+        idx = self.perm[key][self.pos[key]:self.pos[key] + self.N]
+        self.pos[key] += self.N
+        return self.torch.transpose(t.index_select(0, idx), 0, 1)
+
+    def next_batch(self):
+        """dict with the reference's names: batch_rays [2,B,3], target_s [B,3], label_s; batch_inp, target_inp, depth_inp;
+        batch_rays_clf, target_clf, label_s_clf; and with COLMAP depth batch_rays_depth, target_depth, ray_weights"""
+        out = {}
+        b = self._next("rgb")
+        out["batch_rays"], out["target_s"], out["label_s"] = b[:2, :, :-1].contiguous(), b[2, :, :3], b[2, :, 3]
+        b = self._next("inp")
+        out["batch_inp"], out["target_inp"], out["depth_inp"] = b[:2, :, :-1].contiguous(), b[2, :, :3], b[2, :, 3]
+        b = self._next("clf")
+        out["batch_rays_clf"], out["target_clf"], out["label_s_clf"] = b[:2, :, :-1].contiguous(), b[2, :, :3], b[2, :, 3]
+        if "depth" in self.tab:
+            b = self._next("depth")
+            out["batch_rays_depth"], out["target_depth"], out["ray_weights"] = b[:2].contiguous(), b[2, :, 0], b[3, :, 0]
+        return out

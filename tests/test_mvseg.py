@@ -8,12 +8,20 @@ import torch
 from oracle import nerf_oracle as O
 from helpers import load, T
 
-CASES = ["mvseg_r2o_s64", "mvseg_r2o_s192_white"]
+CASES = ["mvseg_r2o_s64", "mvseg_r2o_s192_white", "mvseg_r2o_only_object", "mvseg_r2o_only_object_thr"]
+
+
+def _kw(g):
+    """the only_object arguments of a fixture (MVSeg/DS_NeRF/run_nerf_helpers.py:383-397, 410-411)"""
+    if "only_object" not in g:
+        return {}
+    return dict(only_object=True, threshold=None if float(g["threshold"]) < 0 else float(g["threshold"]),
+                harsh_bg_remove=bool(g["harsh"]))
 
 
 def _check(fn, g, dev, atol):
     raw = T(g["raw"]).to(dev).requires_grad_(True)
-    out = fn(raw, T(g["z_vals"]).to(dev), T(g["rays_d"]).to(dev), white_bkgd=bool(g["white"]))
+    out = fn(raw, T(g["z_vals"]).to(dev), T(g["rays_d"]).to(dev), white_bkgd=bool(g["white"]), **_kw(g))
     names = ["rgb", "disp", "acc", "weights", "depth", "prob", "logits"]
     for n, o in zip(names, out):
         np.testing.assert_allclose(o.detach().cpu().numpy(), g[n], atol=atol, rtol=2e-4 if n in ("disp", "depth") else 1e-5,
@@ -34,4 +42,4 @@ def test_oracle_matches_mvseg_reference(name):
 @pytest.mark.parametrize("name", CASES)
 def test_hip_matches_mvseg_reference(name):
     import spin_nerf_amd as S
-    _check(lambda raw, z, d, white_bkgd: S.raw2outputs_mvseg(raw, z, d, 0, white_bkgd), load(name), "cuda", 2e-6)
+    _check(lambda raw, z, d, white_bkgd, **kw: S.raw2outputs_mvseg(raw, z, d, 0, white_bkgd, **kw), load(name), "cuda", 2e-6)
