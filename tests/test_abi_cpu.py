@@ -148,3 +148,30 @@ def test_create_nerf_with_alpha_model_path(S, tmp_path):
     args.no_coarse = True
     kw_train, _, _, grad_vars, _ = S.create_nerf(args, device=torch.device("cpu"))
     assert kw_train["network_fn"] is None and len(grad_vars) == 2
+
+
+def test_hashgrid_sizes_and_module_contract_on_host(S):
+    """config 5 (NeRF_TCNN): the C ABI's level table agrees with the oracle's restatement of the published definition,
+    and the module exposes tiny-cuda-nn's state-dict keys (run_nerf_helpers_tcnn.py:36-84) — no GPU needed."""
+    from oracle import hashgrid_oracle as H
+    lib = S._lib.load()
+    levels, total = H.level_table()
+    assert lib.snr_hashgrid_table_entries() == total == 7034832
+    assert lib.snr_hashgrid_param_count() == 2 * total + 3072 + 7168
+    assert lib.snr_hashgrid_packed_bytes() == 44 * 1024
+    assert lib.snr_hashgrid_act_bytes(1000) == 32 * 2048 and lib.snr_hashgrid_act_bytes(0) == -2
+    assert lib.snr_hashgrid_bwd_ws_bytes(1024 * 192) > 1024 * 192 * 900
+    assert lib.snr_hashgrid_forward(None, None, None, None, 0, None, None, 0, 8, 1, None, None, None) == -1
+    assert [l[1] for l in levels[:4]] == [16, 31, 57, 107] and [bool(l[4]) for l in levels[:4]] == [False, False, False, True]
+    torch.manual_seed(0)
+    net = S.NeRF_TCNN()
+    sd = net.state_dict()
+    assert list(sd) == ["encoder.params", "sigma_net.params", "encoder_dir.params", "color_net.params"]
+    assert sd["encoder.params"].numel() == 2 * total and float(sd["encoder.params"].abs().max()) <= 1e-4
+    net2 = S.NeRF_TCNN()
+    net2.load_state_dict(sd)
+    assert torch.equal(net2.flat.detach(), net.flat.detach())
+    with pytest.raises(NotImplementedError):
+        S.NeRF_TCNN(hidden_dim=128)
+    with pytest.raises(S.HipLibraryError):            # no CPU fallback on this path either
+        net(torch.zeros(4, 6))
