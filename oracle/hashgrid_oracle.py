@@ -87,6 +87,7 @@ def hash_encode(x01: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
     outs = []
     x = x01.to(torch.float32)
     for scale, res, n, off, hashed in levels:
+        lvl = tab[off:off + n]                 # (slicing first keeps autograd's scatter per level instead of per table)
         # tiny-cuda-nn forms the grid position with ONE rounding (fmaf(scale, x, 0.5f)); at the finest levels pos ~ 2e5 and
         # a second rounding would move the interpolation weights by up to 1 %: the fp64 product and sum are exact
         pos = (x.double() * float(scale) + 0.5).float()
@@ -107,7 +108,7 @@ def hash_encode(x01: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
                 idx = h % n
             else:
                 idx = (c[0] + c[1] * res + c[2] * res * res) % n
-            acc = acc + w.to(tab.dtype)[:, None] * tab[off + idx]
+            acc = acc + w.to(tab.dtype)[:, None] * lvl[idx]
         outs.append(acc)
     return torch.cat(outs, -1)
 

@@ -207,7 +207,7 @@ int snr::wgrad_launch_bf16(const WgradArgs& w, int total_splits, float* grad, in
   }
   int st = launch_status();
   if (st != SNR_OK) return st;
-  const int per_out = 256 * (256 / 4 + 1);
+  const int per_out = 4 * 256 * (256 / 4 + 1);   // 4 lanes per (row, 4-column group | bias) item
   {
     ProfScope ps(K_MLP_WGRAD_REDUCE, s);
     mlp_wgrad_reduce_kernel<kBF16><<<dim3((per_out + 255) / 256, (unsigned)w.n_outs), dim3(256), 0, s>>>(w, grad, accumulate);
@@ -288,7 +288,7 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   }
   st = launch_status();
   if (st != SNR_OK) return st;
-  const int per_out = 256 * (256 / 4 + 1);   // rows x (4-column groups + the bias thread)
+  const int per_out = 4 * 256 * (256 / 4 + 1);   // 4 lanes per item; items = rows x (4-column groups + the bias)
   {
     ProfScope ps(K_MLP_WGRAD_REDUCE, s);
     mlp_wgrad_reduce_kernel<P><<<dim3((per_out + 255) / 256, (unsigned)w.n_outs), dim3(256), 0, s>>>(w, grad, accumulate);

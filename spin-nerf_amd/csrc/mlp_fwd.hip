@@ -26,10 +26,13 @@ __global__ void mlp_pack_kernel(PackTable T, const float* __restrict__ params, c
   constexpr int EPF = Prec<P>::EPF;
   const int total_frags = T.fwd_frags + T.bwd_frags;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int F = (int)(gid >> 6), lane = (int)(gid & 63);
+  // the frag index is wave-uniform: keep the entry search on the scalar unit, all of its loads in flight at once (a
+  // data-dependent while loop here chained up to 26 kernarg loads and was most of this kernel's 19 us)
+  const int F = __builtin_amdgcn_readfirstlane((int)(gid >> 6)), lane = (int)(gid & 63);
   if (F < total_frags) {
     int ei = 0;
-    while (ei + 1 < T.n_entries && T.e[ei + 1].frag_begin <= F) ++ei;
+#pragma unroll
+    for (int k = 1; k < kMaxPackEntries; ++k) ei += (k < T.n_entries && T.e[k].frag_begin <= F) ? 1 : 0;
     const PackEntry& E = T.e[ei];
     const int per_tile = E.src[0].ks + E.src[1].ks;
     const int local = F - E.frag_begin;

@@ -404,36 +404,53 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, i
   // Every parameter element is produced by exactly one (output, row, column): without `accumulate` the result is
   // stored, not added, and the gradient buffer needs no clearing first
   // (tests/test_gpu_kernels.py: test_mlp_backward_overwrites_every_element).
-  // blockIdx.y = output; a thread covers (row, 4 consecutive partial-sum columns); one extra thread per row does
-  // the bias.  16-byte loads, two independent accumulators per element.
+  // blockIdx.y = output.  A 16-lane group covers 16 consecutive work items (row, 4 consecutive partial-sum columns — one
+  // extra item per row is the bias); the wave's four groups each sum every fourth split plane and are combined with two
+  // cross-lane adds, which quadruples the loads in flight of this short, latency-bound kernel.  The summation order is
+  // fixed: results are deterministic.
   const WgradOut& O = a.out[blockIdx.y];
   const WgradJob& J = a.job[O.job];
   const int NA = J.nta * 32, NB = J.ntb * 32, NQ = O.cols / 4;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)O.rows * (NQ + 1)) return;
-  const int ra = (int)(idx / (NQ + 1)), q = (int)(idx % (NQ + 1));
+  const int lane = threadIdx.x & 63, r = lane >> 4;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t idx = wave * 16 + (lane & 15);
+  const int64_t items = (int64_t)O.rows * (NQ + 1);
+  if (wave * 16 >= items) return;                       // wave-uniform: the cross-lane adds below see whole waves
+  const bool live = idx < items;
+  const int ra = live ? (int)(idx / (NQ + 1)) : 0, q = live ? (int)(idx % (NQ + 1)) : 0;
   const int n = slot_true_index<P>(O.a_kind, ra, 0) - (O.a_kind == SRC_OUT ? O.row_off : 0);
-  if (n < 0 || n >= O.rows_valid) return;
+  const bool row_ok = live && n >= 0 && n < O.rows_valid;
   float* dst = O.to_scratch ? a.post : grad;
   const bool acc = accumulate && !O.to_scratch;
-  if (q == NQ) {
-    if (O.bias_off < 0) return;
-    float s = 0.f;
-    for (int sp = 0; sp < J.n_splits; ++sp) s += a.part[J.bias_part_off + (int64_t)sp * NA + O.row0 + ra];
-    dst[O.bias_off + n] = acc ? dst[O.bias_off + n] + s : s;
-    return;
-  }
+  const bool is_bias = q == NQ;
   const int cb = 4 * q;
-  const float* p = a.part + J.part_off + (int64_t)(O.row0 + ra) * NB + O.col0 + cb;
   const int64_t st = (int64_t)NA * NB;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-  int sp = 0;
-  for (; sp + 2 <= J.n_splits; sp += 2) {
-    s0 += *(const f32x4*)(p + (sp + 0) * st);
-    s1 += *(const f32x4*)(p + (sp + 1) * st);
+  if (row_ok && !is_bias) {
+    const float* p = a.part + J.part_off + (int64_t)(O.row0 + ra) * NB + O.col0 + cb;
+    int sp = r;
+    for (; sp + 12 < J.n_splits; sp += 16) {
+      const f32x4 v0 = __builtin_nontemporal_load((const f32x4*)(p + (sp + 0) * st));
+      const f32x4 v1 = __builtin_nontemporal_load((const f32x4*)(p + (sp + 4) * st));
+      const f32x4 v2 = __builtin_nontemporal_load((const f32x4*)(p + (sp + 8) * st));
+      const f32x4 v3 = __builtin_nontemporal_load((const f32x4*)(p + (sp + 12) * st));
+      s0 += v0 + v2; s1 += v1 + v3;
+    }
+    for (; sp < J.n_splits; sp += 4) s0 += __builtin_nontemporal_load((const f32x4*)(p + sp * st));
+  } else if (row_ok && O.bias_off >= 0) {
+    for (int sp = r; sp < J.n_splits; sp += 4) s0[0] += a.part[J.bias_part_off + (int64_t)sp * NA + O.row0 + ra];
   }
-  if (sp < J.n_splits) s0 += *(const f32x4*)(p + sp * st);
-  const f32x4 s = s0 + s1;
+  f32x4 s = s0 + s1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s[e] += __shfl_xor(s[e], 16);
+    s[e] += __shfl_xor(s[e], 32);
+  }
+  if (!row_ok || r != 0) return;
+  if (is_bias) {
+    if (O.bias_off >= 0) dst[O.bias_off + n] = acc ? dst[O.bias_off + n] + s[0] : s[0];
+    return;
+  }
   float* grow = dst + O.w_off + (int64_t)n * O.ld + O.col_off;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {

@@ -1,10 +1,14 @@
 """Camera-pose side of the LLFF ingestion: what `load_llff_data` (DS_NeRF/load_llff.py:315-433) does
 to `poses_bounds.npy` once the files are read — axis reorder, bound rescale, recentering, the "spherify hack", the
 spiral render path, the hold-out view — and the ray table `train()` builds from poses + images
-(run_nerf.py:1225-1262).  Pure numpy, host side; image / mask / depth file reading (cv2, imageio) is not built.
+(run_nerf.py:1225-1262) — plus, further down, the file-reading half (`load_llff_folder`, `minify`), the COLMAP depth
+loader (`load_colmap_depth`, load_llff.py:448-501) and the four shuffled ray feeds of train() (run_nerf.py:1264-1417).
+Pure numpy / PIL, host side.
 
 Pinned by fixtures produced by the reference's own `load_llff_data` with only its file reader replaced by synthetic
-arrays (tests/golden/make_golden_poses.py)."""
+arrays (tests/golden/make_golden_poses.py) and by its `load_colmap_depth` on a synthetic COLMAP model
+(tests/golden/make_golden_colmap.py).  The image / mask / depth file reader itself is parity-UNPINNED: the reference reads
+through imageio and cv2, neither of which is on this image (see the note above `load_llff_folder`)."""
 import os
 
 import numpy as np

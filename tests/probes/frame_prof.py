@@ -1,21 +1,31 @@
-"""Diagnostic: per-kernel time of one full 378x504 frame render (bf16 inference)."""
-import os, sys, time, torch, argparse, tempfile, contextlib, io, importlib
+"""Diagnostic: where a full 378x504 inference frame goes (per-kernel HIP-event times, wall clock, chunk size sweep)."""
+import os, sys, time, contextlib, io
+import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-S = importlib.import_module("spin-nerf_amd")
-sys.argv = [sys.argv[0]]
+import spin_nerf_amd as S
 import bench
-ns = argparse.Namespace(n_fine=128, n_coarse=64, precision="bf16")
+dev = torch.device("cuda")
+H, W, focal, near, far = 378, 504, 400.0, 1.2, 9.0
+torch.manual_seed(0)
+import argparse
+args = bench.make_args(argparse.Namespace(precision="bf16", n_rand=1024, n_coarse=64, n_fine=128))
 with contextlib.redirect_stdout(io.StringIO()):
-    kw_train, kw_test, *_ = S.create_nerf(bench.make_args(ns), device=torch.device("cuda"))
-kw_test.update(near=1.2, far=9.0)
-c2w = torch.eye(4)[:3, :4].cuda()
-with torch.no_grad():
-    for chunk in (32768, 65536, 190512):
-        S.render(378, 504, 400.0, chunk=chunk, c2w=c2w, **kw_test); torch.cuda.synchronize()
-        S._lib.prof_enable(True); S._lib.prof_read()
+    kw_train, kw_test, *_ = S.create_nerf(args, device=dev)
+kw_test.update(near=near, far=far)
+c2w = torch.eye(4)[:3, :4].to(dev)
+for chunk in (32768, 65536, 190512):
+    with torch.no_grad():
+        S.render(H, W, focal, chunk=chunk, c2w=c2w, **kw_test)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        S.render(378, 504, 400.0, chunk=chunk, c2w=c2w, **kw_test); torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        p = S._lib.prof_read(); S._lib.prof_enable(False)
-        print("chunk", chunk, "frame ms", round(dt * 1e3, 1), {k: round(v[0], 2) for k, v in p.items()}, "kernel sum", round(sum(v[0] for v in p.values()), 1))
+        for _ in range(3):
+            S.render(H, W, focal, chunk=chunk, c2w=c2w, **kw_test)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / 3 * 1e3
+        S._lib.prof_enable(True); S._lib.prof_read()
+        S.render(H, W, focal, chunk=chunk, c2w=c2w, **kw_test)
+        torch.cuda.synchronize()
+        prof = S._lib.prof_read(); S._lib.prof_enable(False)
+    tot = sum(ms for ms, c in prof.values())
+    print(f"chunk {chunk}: wall {wall:.2f} ms; kernels {tot:.2f} ms:", {k: (round(ms, 3), c) for k, (ms, c) in prof.items()}, flush=True)

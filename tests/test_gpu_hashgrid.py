@@ -6,6 +6,7 @@ git dependency, requirements.txt:13) and has no fixture in it; the oracle restat
 lists the sources).  What is established here is HIP kernels == that restatement, plus that the path trains."""
 import argparse
 import importlib
+import math
 import tempfile
 
 import numpy as np
@@ -263,3 +264,54 @@ def test_create_nerf_tcnn_contract_and_a_training_step(S):
     with torch.no_grad():
         rgb, disp, acc, depth, ex = S.render(H_, W_, f, chunk=32768, c2w=c2w.to(dev), **kw_test)
     assert tuple(rgb.shape) == (H_, W_, 3) and bool(torch.isfinite(rgb).all())
+
+
+@pytest.mark.timeout(600)
+def test_hash_grid_training_learns_the_analytic_sphere(S):
+    """create_nerf_tcnn's networks under the reference's recipe (ReLU density through raw2outputs with raw_noise_std = 1,
+    the value of the reference's configs; Adam; lrate 1e-2) on the analytic sphere of tests/test_gpu_train.py: 600
+    iterations of 512 rays.  Measured on MI355X over six initialisation seeds (tests/probes/hashgrid_seed_sweep.py,
+    profiles/r02_hashgrid_train.txt): 34.9-36.7 dB over the last 50 iterations, 34.6-36.8 dB for a full-frame render of a
+    training view; without the density noise three of six seeds fall into the all-empty state (sigma <= 0 everywhere: no
+    gradient) after reaching 33 dB — the same property test_gpu_train.py documents for the big MLP.  The CPU oracle
+    trained from the same initial parameters follows the HIP path's curve (17.7 / 25.8 / 27.7 / 29.2 / 30.3 dB vs
+    17.6 / 25.9 / 27.6 / 28.9 / 29.7 dB at iterations 50...250, tests/probes/hashgrid_oracle_train.py)."""
+    import contextlib, io
+    from test_gpu_train import sphere_scene, H as HH, W as WW, FOCAL, NEAR, FAR
+    RenderTrainer = importlib.import_module("spin-nerf_amd.train").RenderTrainer
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        kw_train, kw_test, *_ = S.create_nerf_tcnn(_args(lrate=1e-2, raw_noise_std=1.0), device=dev)
+    kw_train.update(near=NEAR, far=FAR); kw_test.update(near=NEAR, far=FAR)
+    tr = RenderTrainer(kw_train, lrate=1e-2, lrate_decay=250)
+
+    def camera(a):
+        eye = torch.tensor([4 * math.sin(a), 0.6, 4 * math.cos(a)])
+        z = eye / eye.norm()
+        x = torch.linalg.cross(torch.tensor([0., 1., 0.]), z); x = x / x.norm()
+        return torch.cat([torch.stack([x, torch.linalg.cross(z, x), z], 1), eye[:, None]], 1).to(dev)
+    rays_all, tgt_all = [], []
+    for k in range(6):
+        ro, rd = S.get_rays(HH, WW, FOCAL, camera(2 * math.pi * k / 6))
+        rays_all.append(torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0))
+        tgt_all.append(sphere_scene(ro.reshape(-1, 3), rd.reshape(-1, 3), False))
+    rays_all, tgt_all = torch.cat(rays_all, 1), torch.cat(tgt_all, 0)
+    g = torch.Generator().manual_seed(1)
+    ps = []
+    for it in range(600):
+        sel = torch.randint(0, rays_all.shape[1], (512,), generator=g).to(dev)
+        loss, rgb = tr.step(HH, WW, FOCAL, rays_all[:, sel].contiguous(), tgt_all[sel])
+        ps.append(float(-10.0 * torch.log10(torch.mean((rgb - tgt_all[sel]) ** 2))))
+    def view_psnr(c2w):
+        with torch.no_grad():
+            rgb, disp, acc, depth, ex = S.render(HH, WW, FOCAL, chunk=32768, c2w=c2w, **kw_test)
+        ro, rd = S.get_rays(HH, WW, FOCAL, c2w)
+        return float(-10.0 * torch.log10(torch.mean((rgb - sphere_scene(ro, rd, False)) ** 2))), float(acc.mean())
+    seen, acc = view_psnr(camera(0.0))                      # a training camera, rendered without perturbation
+    held_out, _ = view_psnr(camera(2 * math.pi * 0.5 / 6))  # between two training cameras: printed, not gated — six
+    # views do not constrain a 2^19-entry table with 1000 cells per unit length (the oracle recipe overfits the same way)
+    print(f"hash-grid training PSNR: start {np.mean(ps[:5]):.2f} dB, last 50 of 600: {np.mean(ps[-50:]):.2f} dB; full-frame "
+          f"render of a training view {seen:.2f} dB (mean opacity {acc:.3f}), of a held-out view {held_out:.2f} dB")
+    assert np.mean(ps[-50:]) > 30.0, np.mean(ps[-50:])
+    assert seen > 30.0, seen
