@@ -320,6 +320,33 @@ __device__ __forceinline__ HFrag mask_frag(const f32x16& acc, int H, const HFrag
   return __builtin_convertvector(t, HFrag);
 }
 
+// value held by lane Q of this lane's quad: DPP quad_perm [Q,Q,Q,Q] (no LDS crossbar traffic)
+template <int Q> __device__ __forceinline__ int quad_bcast(int x) {
+  return __builtin_amdgcn_update_dpp(x, x, Q * 0x55, 0xf, 0xf, false);
+}
+template <int Q> __device__ __forceinline__ float quad_bcast(float x) {
+  return __int_as_float(quad_bcast<Q>(__float_as_int(x)));
+}
+// One scatter instruction of the table gradient for the cells of quad lane Q's sample: the four lanes of the quad take
+// (x-neighbour corner 2P | 2P+1) x (feature 0 | 1) — lane j: corner 2P + (j >> 1), feature j & 1.
+template <int Q, int P>
+__device__ __forceinline__ void hg_scatter_quad(float* __restrict__ ggrid, const uint32_t idx[8], const float val[16],
+                                                bool active, int j) {
+  const bool act = quad_bcast<Q>((int)active) != 0;
+  const uint32_t i0 = (uint32_t)quad_bcast<Q>((int)idx[2 * P]), i1 = (uint32_t)quad_bcast<Q>((int)idx[2 * P + 1]);
+  const float v0 = quad_bcast<Q>(val[4 * P]), v1 = quad_bcast<Q>(val[4 * P + 1]), v2 = quad_bcast<Q>(val[4 * P + 2]),
+              v3 = quad_bcast<Q>(val[4 * P + 3]);
+  const uint32_t cell = (j & 2) ? i1 : i0;
+  const float v = (j & 2) ? ((j & 1) ? v3 : v2) : ((j & 1) ? v1 : v0);
+  if (act) __hip_atomic_fetch_add(ggrid + 2 * (int64_t)cell + (j & 1), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int Q>
+__device__ __forceinline__ void hg_scatter_sample(float* __restrict__ ggrid, const uint32_t idx[8], const float val[16],
+                                                  bool active, int j) {
+  hg_scatter_quad<Q, 0>(ggrid, idx, val, active, j); hg_scatter_quad<Q, 1>(ggrid, idx, val, active, j);
+  hg_scatter_quad<Q, 2>(ggrid, idx, val, active, j); hg_scatter_quad<Q, 3>(ggrid, idx, val, active, j);
+}
+
 __global__ __launch_bounds__(64 * kHgWaves) void hg_bwd_kernel(HgTable T, const char* __restrict__ blob, HgIn a,
                                                                const float* __restrict__ d_raw,
                                                                const char* __restrict__ act, char* __restrict__ ws,
@@ -426,20 +453,38 @@ __global__ __launch_bounds__(64 * kHgWaves) void hg_bwd_kernel(HgTable T, const 
             const int leader = half ? (__builtin_ctz(half) + 32 * g) : lane;   // an idle half follows itself: no match
             const uint32_t l_lo = __shfl(k_lo, leader, 64), l_hi = __shfl(k_hi, leader, 64);
             const bool match = active && half != 0 && k_lo == l_lo && k_hi == l_hi;
+            // every lane of the half-wave ends up with the sums; the leader's quad issues them: lane j of it takes corner
+            // 2P + (j >> 1), feature j & 1 of the leader's cell (see the request rule below)
+            const bool writer = half != 0 && (lane | 3) == (leader | 3);
+            const int jw = lane & 3;
+            uint32_t l_idx[8];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-              float sum = match ? val[v] : 0.f;
+            for (int c = 0; c < 8; ++c) l_idx[c] = (uint32_t)__shfl((int)idx[c], leader, 64);
 #pragma unroll
-              for (int d = 1; d < 32; d <<= 1) sum += __shfl_xor(sum, d, 64);
-              if (match && lane == leader)
-                __hip_atomic_fetch_add(ggrid + 2 * (int64_t)idx[v >> 1] + (v & 1), sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int P = 0; P < 4; ++P) {
+              float sm[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                sm[e] = match ? val[4 * P + e] : 0.f;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) sm[e] += __shfl_xor(sm[e], d, 64);
+              }
+              const uint32_t cell = (jw & 2) ? l_idx[2 * P + 1] : l_idx[2 * P];
+              const float v = (jw & 2) ? ((jw & 1) ? sm[3] : sm[2]) : ((jw & 1) ? sm[1] : sm[0]);
+              if (writer)
+                __hip_atomic_fetch_add(ggrid + 2 * (int64_t)cell + (jw & 1), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             active = active && !match;
           }
-          if (active) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v)
-              __hip_atomic_fetch_add(ggrid + 2 * (int64_t)idx[v >> 1] + (v & 1), val[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // The atomic unit's rate is per (instruction, 64-byte line) request, not per lane
+          // (tests/probes/atomic_rate.hip: 21 G requests/s from 64 KB to 256 MB targets; lanes of one instruction that fall
+          // into one line cost one request).  The two features of a cell are 8 bytes, and the x-neighbour of a corner with
+          // even x is the next cell (dense levels: always; hashed levels: prime 1 on x keeps idx ^ 1).  So the four lanes of
+          // a quad work together on one of their samples at a time: 16-24 requests per instruction instead of 64.
+          {
+            const int jq = lane & 3;
+            hg_scatter_sample<0>(ggrid, idx, val, active, jq); hg_scatter_sample<1>(ggrid, idx, val, active, jq);
+            hg_scatter_sample<2>(ggrid, idx, val, active, jq); hg_scatter_sample<3>(ggrid, idx, val, active, jq);
           }
         }
       }
