@@ -151,6 +151,30 @@ class NeRF_TCNN(nn.Module):
             viewdirs = f32c(viewdirs)
         return _HashGrid.apply(self.flat, self, pts, rays, z_vals, viewdirs, M, S)
 
+    # ---- the autograd-free training step (train.py: _step_direct; same contract as ops.mlp_train_forward / _backward) --
+    def train_forward(self, rays, z_vals, viewdirs):
+        lib = _lib.load()
+        if viewdirs is None:
+            raise ValueError("NeRF_TCNN needs view directions (run_nerf_helpers_tcnn.py:88)")
+        packed = self.packed_weights()
+        n, S = z_vals.numel(), z_vals.shape[1]
+        raw = torch.empty(z_vals.shape[0], S, 4, device=z_vals.device, dtype=torch.float32)
+        act = torch.empty(lib.snr_hashgrid_act_bytes(n), device=z_vals.device, dtype=torch.uint8)
+        check(lib.snr_hashgrid_forward(ptr(self.flat.detach()), ptr(packed), None, ptr(rays), rays.shape[1], ptr(z_vals),
+                                       ptr(viewdirs), viewdirs.stride(0), n, S, ptr(raw), ptr(act), stream()),
+              "snr_hashgrid_forward")
+        return raw, (packed, act, n, S, rays, z_vals, viewdirs)
+
+    def train_backward(self, saved, d_raw):
+        lib = _lib.load()
+        packed, act, n, S, rays, z_vals, viewdirs = saved
+        g = torch.empty_like(self.flat.data)
+        ws = torch.empty(lib.snr_hashgrid_bwd_ws_bytes(n), device=g.device, dtype=torch.uint8)
+        check(lib.snr_hashgrid_backward(ptr(self.flat.detach()), ptr(packed), None, ptr(rays), rays.shape[1], ptr(z_vals),
+                                        ptr(viewdirs), viewdirs.stride(0), ptr(d_raw), n, S, ptr(act), ptr(ws), ptr(g), 0,
+                                        stream()), "snr_hashgrid_backward")
+        return g
+
     def query(self, inputs, viewdirs=None):
         S = inputs.shape[-2] if inputs.dim() > 1 else 1
         pts = f32c(inputs.detach().reshape(-1, 3))

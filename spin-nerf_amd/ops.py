@@ -390,6 +390,8 @@ def composite_train(raw, z_vals, rays, target, loss, loss_also=None, noise=None,
 
 def mlp_train_forward(net, rays, z_vals, viewdirs):
     """NeRF forward for the autograd-free training step: (raw [N,S,C], saved context for mlp_train_backward)."""
+    if hasattr(net, "train_forward"):          # NeRF_TCNN (hashgrid.py) brings its own kernels
+        return net.train_forward(rays, z_vals, viewdirs)
     lib = _lib.load()
     cfg = net.cfg
     packed = net.packed_weights()
@@ -407,6 +409,8 @@ def mlp_train_forward(net, rays, z_vals, viewdirs):
 
 
 def mlp_train_backward(net, saved, d_raw):
+    if hasattr(net, "train_backward"):
+        return net.train_backward(saved, d_raw)
     lib = _lib.load()
     packed, act, n = saved
     cfg = net.cfg

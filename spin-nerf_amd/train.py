@@ -95,7 +95,7 @@ class RenderTrainer:
     def step(self, H, W, focal, batch_rays, target_s, chunk=1024 * 32, **extra):
         """one optimisation step on this rank's ray shard; returns (loss, rgb) detached.
 
-        The plain configuration (NeRF networks, no sigma_loss / pytest hook, one chunk) runs without torch autograd:
+        The plain configuration (NeRF or NeRF_TCNN networks, no sigma_loss / pytest hook, one chunk) runs without torch autograd:
         every launch of run_nerf.py:1465-1490 + 1611-1612 is issued directly, the random draws are made in-kernel
         (or taken from ``randoms=``), and each network's compositing forward, loss term and compositing backward are
         one kernel (snr_composite_train).  Anything else goes through render() + autograd."""
@@ -123,7 +123,8 @@ class RenderTrainer:
         if os.environ.get("SNR_NO_DIRECT_STEP") == "1" or set(extra) - {"randoms"}:
             return False
         nets = [kw.get('network_fn')] + ([kw.get('network_fine')] if kw.get('N_importance', 0) > 0 else [])
-        if any(type(n) is not NeRF for n in nets) or kw.get('sigma_loss') is not None:
+        from .hashgrid import NeRF_TCNN
+        if any(type(n) not in (NeRF, NeRF_TCNN) for n in nets) or kw.get('sigma_loss') is not None:
             return False
         if not getattr(kw.get('network_query_fn'), "_snr_fused", False) or not batch_rays[1].is_cuda:
             return False
@@ -174,11 +175,12 @@ class RenderTrainer:
                                         offset=draw(), white_bkgd=white)
             rgb = out_f[0]
             g_f = ops.mlp_train_backward(net_f, sv_f, out_f[5])
+            if net_f is not net_c:
+                net_f.flat.grad = g_f
+                if self.world_size > 1:     # like the autograd hook: the fine net's all-reduce runs under the coarse backward
+                    self._start_all_reduce(self.nets.index(net_f), net_f.flat)
             g_c = ops.mlp_train_backward(net_c, sv_c, out_c[5])
-            if net_f is net_c:
-                net_c.flat.grad = g_c + g_f
-            else:
-                net_f.flat.grad, net_c.flat.grad = g_f, g_c
+            net_c.flat.grad = g_c + g_f if net_f is net_c else g_c
         else:
             net_c.flat.grad = ops.mlp_train_backward(net_c, sv_c, out_c[5])
         self.apply_gradients()
