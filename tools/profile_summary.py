@@ -6,6 +6,8 @@ import sys
 from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
+command = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-frame --no-hashgrid"
+write_json = len(sys.argv) <= 4 or sys.argv[4] != "nojson"
 
 
 def find(pattern):
@@ -18,10 +20,10 @@ def short(name):
     return name.split("(")[0][:60]
 
 
-print(f"# rocprofv3 summary `{tag}` — `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-frame`\n")
+print(f"# rocprofv3 summary `{tag}` — `{command}`\n")
 stats = find(f"{tag}_trace/**/*kernel_stats.csv")
 if stats:
-    print("## kernel trace (--kernel-trace --stats), all 13 steps incl. warm-up and the profiled repeat\n")
+    print("## kernel trace (--kernel-trace --stats), every launch of the command (warm-up and profiled repeats included)\n")
     print("| kernel | calls | total ms | avg us | % |")
     print("|---|---|---|---|---|")
     for i, r in enumerate(csv.DictReader(open(stats))):
@@ -52,7 +54,7 @@ print("\nFETCH_SIZE / WRITE_SIZE are in KiB per launch as reported; per MI355X_M
 # machine-readable copy for bench.py's roofline.traffic / hbm_bytes_per_step (per-kernel averages over all launches of
 # the default bench command; launches per step come from bench.py itself)
 import json
-if pmc_json:
+if pmc_json and write_json:
     with open(os.path.join(out, f"{tag}_pmc.json"), "w") as fh:
-        json.dump({"command": "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-frame",
+        json.dump({"command": command,
                    "workload": "bf16, N_rand=1024, 64c+128f", "kernels": pmc_json}, fh, indent=1)
