@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frame", action="store_true")
-    ap.add_argument("--no-hashgrid", action="store_true", help="skip the extra BASELINE config 5 (hash-grid networks) measurement")
+    ap.add_argument("--no-hashgrid", action="store_true", help="skip the extra measurements (BASELINE config 5 hash-grid networks, config 3 iteration)")
     ns = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,6 +222,28 @@ def main():
                     "ms_per_step": th * 1e3, "parity": "unpinned"}
         del htr, hkw
 
+    # BASELINE config 3 minus its unpinned LPIPS / LaMa parts: the reference's 3-render iteration (run_nerf.py:1455-1521 —
+    # unmasked-pixel render, all-pixel render with detached weights, inpainted-disparity render; loss, backward, Adam)
+    # through RenderTrainer.spin_iteration on the headline networks; 3 x N_rand rays per iteration
+    spin = None
+    if not ns.no_hashgrid and rank == 0 and world == 1:
+        d_inp = torch.rand(ns.n_rand, device=device) * 0.5 + 0.2
+
+        def spin_iter(i):
+            (r0, t0_), (r1, t1_), (r2, _) = batches[i % n_batches], batches[(i + 1) % n_batches], batches[(i + 2) % n_batches]
+            trainer.spin_iteration(H, W, focal, r0, t0_, r1, t1_, r2, d_inp, batched=True)
+        for i in range(ns.warmup):
+            spin_iter(i)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for i in range(ns.steps):
+            spin_iter(ns.warmup + i)
+        torch.cuda.synchronize()
+        ts = (time.perf_counter() - ts) / ns.steps
+        spin = {"workload": "SPIn-NeRF iteration = 3 renders of N_rand rays (clf, complete with detach_weights, inpainted "
+                            "disparity) + losses + backward + Adam, LPIPS / COLMAP terms off", "iterations_per_s": 1.0 / ts,
+                "ms_per_iteration": ts * 1e3, "rays_per_s": 3 * ns.n_rand / ts}
+
     if world > 1:   # leave together: rank 0 may still have been rendering its frame
         import torch.distributed as dist
         dist.barrier()
@@ -299,6 +321,8 @@ def main():
     }
     if hashgrid is not None:
         out["also_measured"] = {"hashgrid_config5": hashgrid}
+    if spin is not None:
+        out.setdefault("also_measured", {})["spin_iteration_config3"] = spin
     if not ns.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(ns, H, W, focal, near, far)
         out["speedup_vs_cpu_baseline"] = rays_per_s / out["cpu_baseline"]["value"]
