@@ -220,17 +220,20 @@ template <int P, int WAVES_> struct Pipe {
       }
       lds_read16<(i % BF) * 1024>(w[i % G], cur_base);
     };
-    auto load_bias = [&](int nt) {
+    // init(0) is the LDS address of the stage's first bias tile; tile nt follows 128 bytes per tile, as an instruction
+    // immediate (one address register per stage — an address per tile kept twelve VGPRs live across the whole kernel)
+    auto load_bias = [&](auto NT_) {
       if constexpr (BIAS) {
-        const uint32_t ba = (uint32_t)init(nt);
-        lds_read16<0>(bias[0], ba); lds_read16<32>(bias[1], ba);
-        lds_read16<64>(bias[2], ba); lds_read16<96>(bias[3], ba);
+        constexpr int o = 128 * decltype(NT_)::value;
+        const uint32_t ba = (uint32_t)init(0);
+        lds_read16<o>(bias[0], ba); lds_read16<o + 32>(bias[1], ba);
+        lds_read16<o + 64>(bias[2], ba); lds_read16<o + 96>(bias[3], ba);
       }
     };
     // tile t's bias reads are issued in step (t-1)*K + FB, behind that step's MFMAs and the epilogue of
     // tile t-2 (whose registers they can take) and ahead of that step's fragment read
     constexpr int FB = K > 1 ? 1 : 0;
-    load_bias(0);
+    load_bias(std::integral_constant<int, 0>{});
     static_for<0, G>([&](auto I_) { load(I_); });
     f32x16 prev[NJ];
     static_for<0, NT>([&](auto NT_) {
@@ -284,7 +287,7 @@ template <int P, int WAVES_> struct Pipe {
             for (int j = 0; j < NJ; ++j) finish(nt - 1, j, prev[j]);
           }
         }
-        if constexpr (f == FB && nt + 1 < NT) load_bias(nt + 1);
+        if constexpr (f == FB && nt + 1 < NT) load_bias(std::integral_constant<int, nt + 1>{});
         if constexpr (i + G < NF) load(std::integral_constant<int, i + G>{});
         if (NJ > 1 || (f & 1)) issue_one();   // one DMA piece per ~64 cycles of MFMA
       });
@@ -431,6 +434,11 @@ __device__ __forceinline__ void store_tile_slice(const char* tile_base, const Fr
 template <int P, int KS>
 __device__ __forceinline__ void encode(float x, float y, float z, int L, int g, typename Mma<P>::Frag* out) {
   constexpr int HP = Prec<P>::EPF / 2;
+  // Everything below that depends only on (g, L) — slot indices, axis selectors, 2^k — is invariant across the tile
+  // loop, and the compiler used to hoist all of it out of the kernel's main loop: ~40 values and mask pairs held across
+  // the MFMA chains, i.e. 220-280 SGPR spills and 12-16 VGPR spills to scratch in the chain kernels.  Recomputing them
+  // per call costs a few dozen VALU instructions per 32-sample tile; the opaque copy of g pins them here.
+  asm volatile("" : "+v"(g));
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
     typename Mma<P>::Frag f = Mma<P>::zero();
