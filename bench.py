@@ -96,8 +96,8 @@ def cpu_baseline(ns, H, W, focal, near, far):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--n-rand", type=int, default=1024, help="rays per GPU per step")
     ap.add_argument("--n-coarse", type=int, default=64)
