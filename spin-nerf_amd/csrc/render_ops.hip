@@ -212,6 +212,12 @@ __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ raw,
   sd = wave_sum(sd); sa = wave_sum(sa);
   const float q = sd / sa;
   // disp = 1/max(1e-10, q): d disp/dw_i = -(z_i - q)/acc / q^2 when q > 1e-10, else 0
+  // A ray that hits nothing has acc = 0 and q = 0/0: its disparity is NaN and so is the gradient THROUGH the disparity —
+  // as in the reference.  But without a gradient into the disparity (gP == 0: the map is not part of the loss, autograd
+  // never visits that branch) the term must vanish exactly; 0 * NaN here used to put a NaN into d sigma of every such
+  // ray that had one sample with a tiny positive density (relu' = 1, alpha = 0): noise-free training then died on its
+  // first empty ray (tests/probes/hashgrid_nan_hunt.py, composite_nan.py).
+  const bool use_disp = gP != 0.f;
   const float dq = (q > 1e-10f) ? -gP / (q * q) : ((q != q) ? q : 0.f);
   const float gwhite = white ? -(gr + gg + gb) : 0.f;
 
@@ -248,7 +254,7 @@ __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ raw,
     const float Ti = Tin * excl;
     const float w = a * Ti;
     const float c0 = sigmoidf(r0), c1 = sigmoidf(r1), c2 = sigmoidf(r2);
-    float G = gD * z + gA + gwhite + dq * (z - q) / sa;
+    float G = gD * z + gA + gwhite + (use_disp ? dq * (z - q) / sa : 0.f);
     if (!detach) G += gr * c0 + gg * c1 + gb * c2;
     if (g_w && in) G += g_w[ray * S + i];
     if (!in) G = 0.f;

@@ -24,8 +24,11 @@ for k in range(6):
     rays_all.append(torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0))
     tgt_all.append(sphere_scene(ro.reshape(-1, 3), rd.reshape(-1, 3), False))
 rays_all, tgt_all = torch.cat(rays_all, 1), torch.cat(tgt_all, 0)
-for noise in (0.0, 1.0):
-    for lr in (1e-2, 5e-4):
+import sys
+NOISES = (0.0, 1.0) if len(sys.argv) < 2 else tuple(float(x) for x in sys.argv[1].split(','))
+LRS = (1e-2, 5e-4) if len(sys.argv) < 3 else tuple(float(x) for x in sys.argv[2].split(','))
+for noise in NOISES:
+    for lr in LRS:
         for seed in range(6):
             torch.manual_seed(seed)
             with contextlib.redirect_stdout(io.StringIO()):

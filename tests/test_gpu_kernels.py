@@ -438,3 +438,37 @@ def test_sample_pdf_with_the_reference_signature(S, name):
     close(out, g["out"], atol=2e-5, rtol=1e-5)
     if bool(g["det"]):
         close(S.sample_pdf(bins, w, u.shape[1], det=True), g["out"], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("S_", [8, 64, 192])
+def test_composite_backward_of_a_ray_that_hits_nothing_is_finite(S_):
+    """A ray with zero opacity everywhere has acc = 0, so depth / acc — the disparity — is NaN, as in the reference.  When
+    the disparity is not part of the loss, autograd never visits that branch and the gradient is finite; the kernel's
+    disparity term must then vanish exactly instead of contributing 0 * NaN.  (Found by noise-free training dying on its
+    first empty ray that had one sample with a tiny positive density: relu' = 1, alpha = 0.)"""
+    import spin_nerf_amd as S
+    from oracle import nerf_oracle as O
+    for tiny in (3.7e-8, 1e-30, 1e-40):
+        raw = torch.full((2, S_, 4), -0.05)
+        raw[..., :3] = torch.linspace(-1, 1, S_)[None, :, None]
+        raw[0, S_ // 2 + 1, 3] = tiny           # ray 0: empty, one tiny positive density; ray 1: empty
+        z = torch.linspace(2.0, 6.0, S_)[None].repeat(2, 1)
+        rays = torch.zeros(2, 11); rays[:, 5] = -1.0; rays[:, 10] = -1.0
+        tgt = torch.tensor([[0.2, 0.4, 0.6], [0.1, 0.1, 0.1]])
+        loss = torch.zeros(2, device="cuda")
+        out = S.ops.composite_train(raw.cuda(), z.cuda(), rays.cuda(), tgt.cuda(), loss[0:1], None, noise=None, noise_std=0.0,
+                                    seed=1, offset=1, white_bkgd=False)
+        rr = raw.clone().requires_grad_(True)
+        o = O.raw2outputs(rr, z, rays[:, 3:6])
+        O.img2mse(o[0], tgt).backward()
+        assert bool(torch.isfinite(rr.grad).all())
+        got = out[5].cpu()
+        assert bool(torch.isfinite(got).all()), torch.nonzero(~torch.isfinite(got))
+        np.testing.assert_allclose(got.numpy(), rr.grad.numpy(), atol=1e-9)
+        assert bool(torch.isnan(out[1]).all())    # the disparity of an empty ray IS NaN (helpers:392 with acc = 0)
+        # the autograd route (render()'s compositing Function) on the same rays
+        r2 = raw.clone().cuda().requires_grad_(True)
+        rgb, disp, acc, w, depth, _ = S.raw2outputs(r2, z.cuda(), rays[:, 3:6].cuda())
+        S.img2mse(rgb, tgt.cuda()).backward()
+        assert bool(torch.isfinite(r2.grad).all())
+        np.testing.assert_allclose(r2.grad.cpu().numpy(), rr.grad.numpy(), atol=1e-9)
