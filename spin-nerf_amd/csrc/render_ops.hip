@@ -121,6 +121,9 @@ __device__ __forceinline__ float noise_at(const NoiseSrc& ns, int64_t e) {
   return ns.arr ? ns.arr[e] : (ns.use_rng ? rng_normal(ns.rng, e) * ns.std : 0.f);
 }
 
+// F.relu as torch evaluates it: a NaN density stays NaN (fmaxf would return 0 and hide a broken network behind "empty space")
+__device__ __forceinline__ float relu_nan(float x) { return (x > 0.f || x != x) ? x : 0.f; }
+
 struct CompMaps { float r, g, b, disp, acc, depth; };   // the same values in every lane
 
 // forward of one ray by one wave: weights (and alpha) to memory, the maps returned
@@ -142,7 +145,7 @@ __device__ __forceinline__ CompMaps composite_fwd_ray(const float* __restrict__ 
       c0 = sigmoidf(rw[0]); c1 = sigmoidf(rw[1]); c2 = sigmoidf(rw[2]);
       const float s = rw[3] + noise_at(ns, ray * S + i);
       // alpha_in: the caller's own opacities (MVSeg's only_object post-processing) instead of helpers:364,382
-      const float a = alpha_in ? alpha_in[ray * S + i] : 1.f - expf(-fmaxf(s, 0.f) * dist);
+      const float a = alpha_in ? alpha_in[ray * S + i] : 1.f - expf(-relu_nan(s) * dist);
       if (alpha_out) alpha_out[ray * S + i] = a;
       one_m = 1.f - a + 1e-10f;
       w = a;
@@ -199,7 +202,7 @@ __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ raw,
       z = zr[i];
       const float dist = ((i + 1 < S) ? (zr[i + 1] - z) : 1e10f) * dn;
       const float s = raw[(ray * S + i) * C + 3] + noise_at(ns, ray * S + i);
-      a = alpha_in ? alpha_in[ray * S + i] : 1.f - expf(-fmaxf(s, 0.f) * dist);
+      a = alpha_in ? alpha_in[ray * S + i] : 1.f - expf(-relu_nan(s) * dist);
       one_m = 1.f - a + 1e-10f;
     }
     const float incl = wave_incl_scan_mul(one_m, lane);
@@ -232,7 +235,7 @@ __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ raw,
       const float z2 = zr[i2];
       const float dist2 = ((i2 + 1 < S) ? (zr[i2 + 1] - z2) : 1e10f) * dn;
       const float s2 = raw[(ray * S + i2) * C + 3] + noise_at(ns, ray * S + i2);
-      const float a2 = alpha_in ? alpha_in[ray * S + i2] : 1.f - expf(-fmaxf(s2, 0.f) * dist2);
+      const float a2 = alpha_in ? alpha_in[ray * S + i2] : 1.f - expf(-relu_nan(s2) * dist2);
       const float incl2 = wave_incl_scan_mul(1.f - a2 + 1e-10f, lane);
       Tin = Tin * __shfl(incl2, kWave - 1, kWave);
     }
@@ -245,7 +248,7 @@ __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ raw,
       const float* rw = raw + (ray * S + i) * C;
       r0 = rw[0]; r1 = rw[1]; r2 = rw[2];
       s = rw[3] + noise_at(ns, ray * S + i);
-      a = alpha_in ? alpha_in[ray * S + i] : 1.f - expf(-fmaxf(s, 0.f) * dist);
+      a = alpha_in ? alpha_in[ray * S + i] : 1.f - expf(-relu_nan(s) * dist);
       one_m = 1.f - a + 1e-10f;
     }
     const float incl = wave_incl_scan_mul(one_m, lane);

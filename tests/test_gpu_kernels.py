@@ -472,3 +472,21 @@ def test_composite_backward_of_a_ray_that_hits_nothing_is_finite(S_):
         S.img2mse(rgb, tgt.cuda()).backward()
         assert bool(torch.isfinite(r2.grad).all())
         np.testing.assert_allclose(r2.grad.cpu().numpy(), rr.grad.numpy(), atol=1e-9)
+
+
+def test_composite_propagates_a_nan_density_like_torch_relu():
+    """F.relu(NaN) is NaN in the reference (helpers:385): a network that has blown up shows as a NaN render and a NaN loss,
+    not as silently empty space (fmaxf(NaN, 0) = 0 did exactly that and hid the bug fixed above)."""
+    import spin_nerf_amd as S
+    from oracle import nerf_oracle as O
+    rs = np.random.RandomState(0)
+    raw = torch.from_numpy(rs.normal(size=(3, 64, 4)).astype(np.float32))
+    raw[1, 10, 3] = float("nan")
+    z = torch.sort(torch.from_numpy(rs.uniform(2, 6, size=(3, 64)).astype(np.float32)), -1)[0]
+    d = torch.from_numpy(rs.normal(size=(3, 3)).astype(np.float32))
+    rgb, disp, acc, w, depth, _ = S.raw2outputs(raw.cuda(), z.cuda(), d.cuda())
+    ref = O.raw2outputs(raw, z, d)
+    assert bool(torch.isnan(ref[0][1]).all()) and bool(torch.isnan(rgb[1]).all()) and bool(torch.isnan(acc[1]))
+    for k in (0, 2):
+        np.testing.assert_allclose(rgb[k].cpu().numpy(), ref[0][k].numpy(), atol=2e-6)
+        assert bool(torch.isfinite(acc[k]))
