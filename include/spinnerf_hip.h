@@ -183,6 +183,62 @@ int snr_composite_train(const float* raw, int raw_ch, const float* z_vals, const
                         float* disp_map, float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss,
                         float* loss_also, snr_stream_t stream);
 
+/* ---- render_rays as ONE call (render_rays_fused_forward / _backward): the launch sequence of
+ * run_nerf.py:593-737 — stratified sampling, coarse network, compositing, hierarchical sampling + sort, fine network,
+ * compositing — enqueued by the library on `stream`, every intermediate in one caller-provided workspace; with `target`
+ * also the loss terms of run_nerf.py:1482-1490 and the compositing backward (snr_composite_train), after which
+ * snr_render_rays_fused_backward runs autograd's part: both networks' parameter gradients.  One network evaluation =
+ * snr_mlp_forward (kind SNR_NET_MLP) or snr_hashgrid_forward (SNR_NET_HASHGRID); fine == NULL with n_importance > 0
+ * evaluates the coarse network twice (run_nerf.py:705). ---- */
+#define SNR_NET_MLP 0
+#define SNR_NET_HASHGRID 1
+typedef struct snr_net {
+  int kind;              /* SNR_NET_* */
+  snr_mlp_config mlp;    /* kind == SNR_NET_MLP */
+  const void* packed;    /* snr_mlp_pack / snr_hashgrid_pack output */
+  const float* params;   /* the flat fp32 parameters `packed` was built from */
+} snr_net;
+typedef struct snr_render_config {
+  int n_samples;         /* N_samples */
+  int n_importance;      /* N_importance (0 = coarse pass only) */
+  int lindisp;           /* --lindisp */
+  int white_bkgd;        /* --white_bkgd */
+  int perturb;           /* perturb > 0: stratified / hierarchical draws are random */
+  float raw_noise_std;   /* --raw_noise_std */
+} snr_render_config;
+/* byte offsets inside the workspace of the tensors render_rays returns in its dict (run_nerf.py:715-726) and of the
+ * intermediates the backward consumes; -1 = absent in this configuration */
+typedef struct snr_render_ws_layout {
+  int64_t z_coarse, raw0, weights0, depth0;  /* [n,Nc], [n,Nc,C], [n,Nc], [n] */
+  int64_t z_vals, raw, weights, z_samples;   /* [n,Nc+Nf], [n,Nc+Nf,C], [n,Nc+Nf], [n,Nf] (n_importance > 0) */
+  int64_t d_raw0, d_raw, act0, act, bwd_ws;  /* training only */
+  int64_t total;                             /* bytes for inference (train == 0) or training */
+} snr_render_ws_layout;
+int snr_render_rays_fused_layout(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine, int64_t n_rays,
+                                 int train, snr_render_ws_layout* out);
+/* rays: packed rows (snr_pack_rays / snr_make_rays).  Random draws: t_rand [n,Nc], u [n,Nf], noise0 [n,Nc], noise
+ * [n,Nc+Nf] (pre-scaled) when non-NULL, else Philox draws with offsets offset+1 (t_rand), +2 (noise0), +3 (u), +4 (noise)
+ * under `seed` when the configuration asks for random numbers (the call always consumes four offsets).
+ * target [n,3] non-NULL = training: loss[0] += mse(rgb, target) + mse(rgb0, target) terms over 3 * n_rays_global
+ * elements, loss[1] += the final map's term alone (zero both first); the workspace then holds what the backward needs.
+ * Outputs (all required): rgb/disp/acc/depth maps of the final pass, rgb0/disp0/acc0 of the coarse pass and z_std [n]
+ * (written only when n_importance > 0). */
+int snr_render_rays_fused_forward(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine,
+                                  const float* rays, int ray_ld, int64_t n_rays, const float* t_rand, const float* u,
+                                  const float* noise0, const float* noise, uint64_t seed, uint64_t offset,
+                                  const float* target, int64_t n_rays_global, void* ws, float* rgb_map, float* disp_map,
+                                  float* acc_map, float* depth_map, float* rgb0, float* disp0, float* acc0, float* z_std,
+                                  float* loss, snr_stream_t stream);
+/* parameter gradients of the training forward above (same cfg / networks / rays / ws): grad_coarse and grad_fine (flat
+ * fp32) overwritten if accumulate == 0, else += ; fine == NULL: both passes accumulate into grad_coarse.
+ * passes: SNR_PASS_FINE | SNR_PASS_COARSE — a data-parallel caller runs the fine pass, starts that network's all-reduce
+ * and then runs the coarse pass; the fine pass goes first whenever both are asked for (autograd's order). */
+#define SNR_PASS_COARSE 1
+#define SNR_PASS_FINE 2
+int snr_render_rays_fused_backward(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine,
+                                   const float* rays, int ray_ld, int64_t n_rays, void* ws, float* grad_coarse,
+                                   float* grad_fine, int accumulate, int passes, snr_stream_t stream);
+
 /* ---- rays: replaces get_rays + ndc_rays + the ray packing of render() (helpers:249-300,
  * run_nerf.py:117-153).  Writes rows [o(3) d(3) near far (viewdirs(3))] for the pixel rectangle
  * [i0,i0+h) x [j0,j0+w) of an H x W pinhole camera with pose c2w_host (12 floats, HOST memory). */

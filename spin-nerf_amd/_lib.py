@@ -31,6 +31,25 @@ class MlpConfig(_c.Structure):
 
 _CFG = _c.POINTER(MlpConfig)
 
+NET_MLP, NET_HASHGRID = 0, 1
+
+
+class Net(_c.Structure):            # snr_net
+    _fields_ = [("kind", _i), ("mlp", MlpConfig), ("packed", _p), ("params", _p)]
+
+
+class RenderConfig(_c.Structure):   # snr_render_config
+    _fields_ = [("n_samples", _i), ("n_importance", _i), ("lindisp", _i), ("white_bkgd", _i), ("perturb", _i),
+                ("raw_noise_std", _f)]
+
+
+class RenderWsLayout(_c.Structure):  # snr_render_ws_layout
+    _fields_ = [(k, _l) for k in ("z_coarse", "raw0", "weights0", "depth0", "z_vals", "raw", "weights", "z_samples", "d_raw0",
+                                  "d_raw", "act0", "act", "bwd_ws", "total")]
+
+
+_NET, _RCFG = _c.POINTER(Net), _c.POINTER(RenderConfig)
+
 # name -> (restype, argtypes); mirrors include/spinnerf_hip.h one to one
 SIGNATURES = {
     "snr_abi_version": (_i, []),
@@ -60,6 +79,10 @@ SIGNATURES = {
     "snr_sample_fine_rng": (_i, [_p, _p, _l, _i, _i, _c.c_uint64, _c.c_uint64, _p, _p, _p, _p]),
     "snr_composite_train": (_i, [_p, _i, _p, _p, _i, _p, _f, _c.c_uint64, _c.c_uint64, _l, _i, _i, _i, _p, _l, _p, _p, _p, _p,
                                  _p, _p, _p, _p, _p]),
+    "snr_render_rays_fused_layout": (_i, [_RCFG, _NET, _NET, _l, _i, _c.POINTER(RenderWsLayout)]),
+    "snr_render_rays_fused_forward": (_i, [_RCFG, _NET, _NET, _p, _i, _l, _p, _p, _p, _p, _c.c_uint64, _c.c_uint64, _p, _l, _p,
+                                           _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "snr_render_rays_fused_backward": (_i, [_RCFG, _NET, _NET, _p, _i, _l, _p, _p, _p, _i, _i, _p]),
     "snr_make_rays": (_i, [_i, _i, _f, _c.POINTER(_f), _i, _i, _i, _i, _i, _f, _f, _i, _p, _i, _p]),
     "snr_sample_pdf": (_i, [_p, _p, _p, _l, _i, _i, _p, _p]),
     "snr_pack_rays": (_i, [_p, _p, _p, _l, _i, _i, _f, _i, _f, _f, _f, _p, _p, _p, _i, _p, _i, _p]),

@@ -24,6 +24,7 @@ SOURCES = [
     ("render_ops.hip", ["-ffp-contract=off"]),
     ("hashgrid.hip", ["-munsafe-fp-atomics"]),   # table gradients: hardware global_atomic_add_f32, no CAS loops
     ("prof.cpp", ["-x", "hip"]),
+    ("fused.cpp", ["-x", "hip"]),                # render_rays as one call: launch order only, no kernels
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 

@@ -425,6 +425,84 @@ def mlp_train_backward(net, saved, d_raw):
 
 
 # ----------------------------------------------------------------------------------------------
+# render_rays as one library call (snr_render_rays_fused_*): the training step's launch sequence is enqueued by the
+# library, every intermediate lives in one workspace
+# ----------------------------------------------------------------------------------------------
+class FusedRender:
+    """handle of one fused training forward: the workspace the backward consumes and views of what it holds"""
+
+    def __init__(self, rc, nets, keep, rays, n, ws, layout, maps, loss):
+        self.rc, self.nets, self.keep, self.rays, self.n, self.ws, self.layout = rc, nets, keep, rays, n, ws, layout
+        self.rgb, self.disp, self.acc, self.depth, self.rgb0, self.disp0, self.acc0, self.z_std = maps
+        self.loss = loss
+
+    def view(self, name, *shape):
+        """tensor view of a workspace section ('z_vals', 'weights', 'raw', 'z_coarse', 'weights0', 'raw0', 'z_samples')"""
+        off = getattr(self.layout, name)
+        if off < 0:
+            raise KeyError(name)
+        count = 1
+        for d in shape:
+            count *= d
+        return self.ws[off:off + 4 * count].view(torch.float32).view(*shape)
+
+
+def _net_struct(net):
+    packed = net.packed_weights()
+    if hasattr(net, "cfg"):
+        s = _lib.Net(_lib.NET_MLP, net.cfg, ptr(packed), ptr(net.flat.detach()))
+    else:
+        s = _lib.Net(_lib.NET_HASHGRID, _lib.MlpConfig(), ptr(packed), ptr(net.flat.detach()))
+    return s, packed
+
+
+def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bkgd, perturb, raw_noise_std, seed, offset,
+                  target, loss, n_rays_global=None, randoms=None):
+    """render_rays + the loss terms + the compositing backward of one training step in one library call.  ``net_f`` None
+    with N_importance > 0 = the coarse network evaluated twice.  Consumes the Philox offsets offset+1 .. offset+4.
+    Returns a FusedRender; fused_backward(handle) gives the parameter gradients."""
+    import ctypes
+    lib = _lib.load()
+    rnd = randoms or {}
+    n = rays.shape[0]
+    rc = _lib.RenderConfig(int(N_samples), int(N_importance), int(bool(lindisp)), int(bool(white_bkgd)),
+                           int(perturb > 0.), float(raw_noise_std))
+    sc, pc = _net_struct(net_c)
+    two = N_importance > 0 and net_f is not None and net_f is not net_c
+    sf, pf = _net_struct(net_f) if two else (None, None)
+    L = _lib.RenderWsLayout()
+    fptr = ctypes.byref(sf) if two else None
+    check(lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(sc), fptr, n, 1, ctypes.byref(L)),
+          "snr_render_rays_fused_layout")
+    dev = rays.device
+    ws = torch.empty(L.total, device=dev, dtype=torch.uint8)
+    maps8 = torch.empty(8, n, 3, device=dev, dtype=torch.float32)      # one allocation for the eight output maps
+    rgb, rgb0 = maps8[0], maps8[1]
+    flat = maps8.view(8, -1)
+    disp, acc, depth, disp0, acc0, z_std = (flat[2 + k, :n] for k in range(6))   # the first n floats of a slab each
+    arr = {k: (f32c(rnd[k]) if rnd.get(k) is not None else None) for k in ("t_rand", "u", "noise_c", "noise_f")}
+    check(lib.snr_render_rays_fused_forward(
+        ctypes.byref(rc), ctypes.byref(sc), fptr, ptr(rays), rays.shape[1], n, ptr(arr["t_rand"]), ptr(arr["u"]),
+        ptr(arr["noise_c"]), ptr(arr["noise_f"]), int(seed), int(offset), ptr(target), int(n_rays_global or n), ptr(ws),
+        ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(rgb0), ptr(disp0), ptr(acc0), ptr(z_std), ptr(loss), stream()),
+        "snr_render_rays_fused_forward")
+    return FusedRender(rc, (sc, sf), (pc, pf, arr), rays, n, ws, L, (rgb, disp, acc, depth, rgb0, disp0, acc0, z_std), loss)
+
+
+PASS_COARSE, PASS_FINE = 1, 2
+
+
+def fused_backward(h, grad_c, grad_f=None, accumulate=False, passes=PASS_COARSE | PASS_FINE):
+    """parameter gradients of a fused training forward into the flat buffers grad_c / grad_f"""
+    import ctypes
+    lib = _lib.load()
+    sc, sf = h.nets
+    check(lib.snr_render_rays_fused_backward(ctypes.byref(h.rc), ctypes.byref(sc), ctypes.byref(sf) if sf is not None else None,
+                                             ptr(h.rays), h.rays.shape[1], h.n, ptr(h.ws), ptr(grad_c), ptr(grad_f),
+                                             int(bool(accumulate)), int(passes), stream()), "snr_render_rays_fused_backward")
+
+
+# ----------------------------------------------------------------------------------------------
 # Adam on a flat buffer (run_nerf.py:433-434)
 # ----------------------------------------------------------------------------------------------
 def adam_step_(params, grads, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):

@@ -147,6 +147,26 @@ class RenderTrainer:
         loss = torch.zeros(2, device=rays.device)      # [0] = the step's loss, [1] = the final render's term alone
         seed = self._seed
 
+        if os.environ.get("SNR_NO_FUSED_STEP") != "1":
+            # the whole launch sequence as two library calls (snr_render_rays_fused_forward / _backward)
+            two = Nf > 0 and net_f is not net_c
+            h = ops.fused_forward(net_c, net_f if two else None, rays, Nc, Nf, lindisp, white, perturb, std, seed, self._draws,
+                                  target, loss, randoms=rnd)   # local mean: Adam folds 1 / world_size in
+            self._draws += 4
+            g_c = torch.empty_like(net_c.flat.data)
+            if two:
+                g_f = torch.empty_like(net_f.flat.data)
+                ops.fused_backward(h, g_c, g_f, passes=ops.PASS_FINE)
+                net_f.flat.grad = g_f
+                if self.world_size > 1:     # the fine net's all-reduce runs under the coarse backward
+                    self._start_all_reduce(self.nets.index(net_f), net_f.flat)
+                ops.fused_backward(h, g_c, g_f, passes=ops.PASS_COARSE)
+            else:
+                ops.fused_backward(h, g_c)
+            net_c.flat.grad = g_c
+            self.apply_gradients()
+            return loss[0], h.rgb
+
         def draw():
             self._draws += 1
             return self._draws

@@ -180,3 +180,22 @@ def test_in_kernel_random_draws():
     assert torch.equal(outs[0][4], outs[1][4]) and torch.equal(outs[0][5], outs[1][5])      # same (seed, offset): same draws
     assert float((outs[0][4][:, 0] != outs[2][4][:, 0]).float().mean()) > 0.4               # next offset: new draws
     assert bool(torch.isfinite(outs[0][5]).all())
+
+
+@pytest.mark.parametrize("Nf", [128, 0])
+def test_fused_library_step_equals_the_per_kernel_step(monkeypatch, Nf):
+    """snr_render_rays_fused_forward / _backward (the default route of RenderTrainer.step) enqueue exactly the launches the
+    per-kernel route issues from Python: same in-kernel draws (offsets +1..+4), same workspace contents — render, gradients
+    and the updated parameters must be bit-identical."""
+    (a, b), hwf, rays, target, _ = _two_trainers("bf16", Nf)
+    assert a[0]._direct_ok(rays, 32768, {})
+    la, rgb_a = a[0].step(*hwf, rays, target)
+    monkeypatch.setenv("SNR_NO_FUSED_STEP", "1")
+    lb, rgb_b = b[0].step(*hwf, rays, target)
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))     # (the loss is summed by one atomic per workgroup)
+    assert torch.equal(rgb_a, rgb_b)
+    for na, nb in zip(a[1], b[1]):
+        if nb.flat.grad is None:
+            continue
+        assert torch.equal(na.flat.grad, nb.flat.grad)
+        assert torch.equal(na.flat.detach(), nb.flat.detach())
