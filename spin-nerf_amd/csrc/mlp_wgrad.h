@@ -95,7 +95,8 @@ struct WgradLocal {   // (scalar members, no arrays: a select between two array 
   float* part;
   float* bias_part;
   int a_ks, b_ks, ntb_total;
-  int64_t t0, t1;    // tile range of this split
+  int64_t t0, t1;    // first tile of this split, number of its tiles
+  int tstep;         // distance between consecutive tiles of this split
 };
 
 // 8 waves per workgroup = two per SIMD: while one wave sits in the vector-memory issue queue (DMA)
@@ -161,10 +162,10 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
     const char* base = isA ? (second ? a1b : a0b) : (second ? b1b : b0b);
     const int ks = isA ? (second ? a1k : a0k) : (second ? b1k : b0k);
     src[k] = base + (L.t0 * ks + q) * 1024 + lane * 16;
-    stride[k] = ks * 1024;
+    stride[k] = ks * 1024 * L.tstep;
     lds_off[k] = p * 1024;
   }
-  int64_t src_tile = L.t0;
+  int64_t src_tile = 0;      // tiles issued so far (tile k of this workgroup = t0 + k * tstep)
   // Piece indices are compile-time constants everywhere: a run-time index into src[] / lds_off[] would put the arrays
   // into scratch memory, and every scratch load is a vector-memory load the compiler waits for with vmcnt(0) — i.e. it
   // would drain the DMA queue.
@@ -181,7 +182,7 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
 #if defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 4   // timing experiment: the stream re-reads one tile (L2 hits)
     if (false) {
 #else
-    if (src_tile + 1 < L.t1) {
+    if (src_tile + 1 < L.t1) {   // t1 = number of tiles of this workgroup
 #endif
       ++src_tile;
 #pragma unroll
@@ -223,7 +224,7 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
   }
 #endif
   int slot = 0, islot = D % R;
-  for (int64_t tile = L.t0; tile < L.t1; ++tile) {
+  for (int64_t tile = 0; tile < L.t1; ++tile) {
 #if defined(SNR_WGRAD_ABLATE) && SNR_WGRAD_ABLATE == 2   // timing experiment: compute on whatever is in LDS
     __builtin_amdgcn_s_barrier();
 #else
@@ -337,8 +338,20 @@ __global__ __launch_bounds__(64 * kWgradWaves) void mlp_wgrad_kernel(WgradArgs a
   L.b0_base = a.act + J.b[0].off; L.b0_ks = J.b[0].ks;
   L.b1_base = a.act + J.b[1].off; L.b1_ks = J.b[1].ks;
   L.a_ks = J.a_ks; L.b_ks = J.b_ks; L.ntb_total = J.ntb;
-  L.t0 = a.n_tiles * split / J.n_splits;
-  L.t1 = a.n_tiles * (split + 1) / J.n_splits;
+#ifndef SNR_WGRAD_STRIDED
+#define SNR_WGRAD_STRIDED 1
+#endif
+#if SNR_WGRAD_STRIDED
+  // split s takes tiles s, s + n_splits, s + 2 n_splits ...: at any moment the workgroups of a job read neighbouring
+  // tiles, so each section is swept once front to back by the whole chip (the access pattern of a plain streaming read)
+  // instead of by n_splits separate sequential streams
+  L.t0 = split; L.tstep = J.n_splits;
+  L.t1 = (a.n_tiles - split + J.n_splits - 1) / J.n_splits;
+  if (L.t1 <= 0) { L.t0 = 0; L.t1 = 0; }   // more splits than tiles: the pipeline prologue still reads one (valid) tile
+#else
+  L.t0 = a.n_tiles * split / J.n_splits; L.tstep = 1;
+  L.t1 = a.n_tiles * (split + 1) / J.n_splits - L.t0;
+#endif
   const int nta = J.nta, ntb = J.ntb;
   L.part = a.part + J.part_off + (int64_t)split * nta * 32 * ntb * 32;
   L.bias_part = a.part + J.bias_part_off + (int64_t)split * nta * 32;
