@@ -66,16 +66,17 @@ def train(precision, iters, n_rand=1024, seed=0, white=False, noise=1.0):
         loss, rgb = tr.step(H, W, FOCAL, rays_all[:, sel].contiguous(), tgt_all[sel])
         mse = torch.mean((rgb - tgt_all[sel]) ** 2)
         psnrs.append(float(-10.0 * torch.log10(mse)))
-    # held-out view, deterministic render
-    a = 2 * math.pi * 0.5 / 6
-    eye = torch.tensor([4 * math.sin(a), 0.6, 4 * math.cos(a)])
-    z = eye / eye.norm(); x = torch.linalg.cross(torch.tensor([0., 1., 0.]), z); x = x / x.norm(); y = torch.linalg.cross(z, x)
-    c2w = torch.cat([torch.stack([x, y, z], 1), eye[:, None]], 1).to(dev)
-    with torch.no_grad():
-        rgb, *_ = S.render(H, W, FOCAL, chunk=32768, c2w=c2w, **kw_test)
-    ro, rd = S.get_rays(H, W, FOCAL, c2w)
-    test_psnr = float(-10.0 * torch.log10(torch.mean((rgb - sphere_scene(ro, rd, white)) ** 2)))
-    return psnrs, test_psnr
+    # deterministic full-frame renders (perturb = 0, no density noise): a training camera and a held-out view
+    def view_psnr(a):
+        eye = torch.tensor([4 * math.sin(a), 0.6, 4 * math.cos(a)])
+        z = eye / eye.norm(); x = torch.linalg.cross(torch.tensor([0., 1., 0.]), z); x = x / x.norm(); y = torch.linalg.cross(z, x)
+        c2w = torch.cat([torch.stack([x, y, z], 1), eye[:, None]], 1).to(dev)
+        with torch.no_grad():
+            rgb, *_ = S.render(H, W, FOCAL, chunk=32768, c2w=c2w, **kw_test)
+        ro, rd = S.get_rays(H, W, FOCAL, c2w)
+        return float(-10.0 * torch.log10(torch.mean((rgb - sphere_scene(ro, rd, white)) ** 2)))
+    train.seen_view_psnr = view_psnr(0.0)
+    return psnrs, view_psnr(2 * math.pi * 0.5 / 6)
 
 
 @pytest.mark.timeout(900)
@@ -94,10 +95,14 @@ def test_bf16_training_matches_fp32_psnr():
     both paths above 24 dB."""
     iters = 1200
     p32, t32 = train("fp32", iters)
+    s32 = train.seen_view_psnr
     p16, t16 = train("bf16", iters)
+    s16 = train.seen_view_psnr
     tail32, tail16 = float(np.mean(p32[-400:])), float(np.mean(p16[-400:]))
     print(f"train PSNR (last 400 of {iters}): fp32 {tail32:.2f} dB, bf16 {tail16:.2f} dB; "
           f"held-out view: fp32 {t32:.2f} dB, bf16 {t16:.2f} dB; start {np.mean(p32[:5]):.2f} dB")
+    print(f"deterministic full-frame render of a training camera: fp32 {s32:.2f} dB, bf16 {s16:.2f} dB")
+    assert s32 > 22.0 and s16 > 22.0, "the inference path does not reproduce what was trained"
     assert tail32 > 24.0, "fp32 path did not learn the scene"
     assert tail16 > 24.0, "bf16 path did not learn the scene"
     assert abs(tail16 - tail32) < 0.6, (tail16, tail32)
