@@ -269,7 +269,7 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
               tr_wait<2 * (NTB - 1 - y)>(blo[y], bhi[y]);
             }
             const Frag fb = Frag{blo[y][0], blo[y][1], blo[y][2], blo[y][3], bhi[y][0], bhi[y][1], bhi[y][2], bhi[y][3]};
-            acc[0][y] = M::mma(fa, fb, acc[0][y]);
+            acc[0][y] = M::mma(fb, fa, acc[0][y]);   // transposed tile: a lane holds 16 k-columns of ONE output row (see the stores)
             if constexpr (NTB < 8 || (y & 1)) { SNR_WGRAD_ISSUE(half * kPerHalf + (NTB < 8 ? y : y / 2)); }
           });
         });
@@ -290,7 +290,7 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
 #pragma unroll
           for (int y = 0; y < NTB; ++y) {
             const float fb = elem(fb_base, b_ks, y, sidx);
-            acc[0][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[0][y], 0, 0, 0);
+            acc[0][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb, fa, acc[0][y], 0, 0, 0);
           }
           SNR_WGRAD_ISSUE(ks2);
         });
@@ -308,12 +308,17 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
   if constexpr (NX > 0) {
     // partials: [nta*32][ntb*32] row-major for this split
     const int NB = L.ntb_total * 32;
+    // The MFMAs were issued with the operands swapped, so the accumulator tile is dW^T: lane (i32, g32) holds output row
+    // 32 ta0 + i32 and, in registers 4k..4k+3, its columns 32 y + 8 k + 4 g32 + 0..3 — four neighbours of the row-major
+    // partial plane, i.e. one 16-byte store instead of four 4-byte ones (the 160 scalar stores per wave were a visible
+    // tail of this kernel).
+    float* prow = L.part + (int64_t)(32 * ta0 + i32) * NB + 4 * g32;
 #pragma unroll
     for (int y = 0; y < NTB; ++y) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * ta0 + (r & 3) + 8 * (r >> 2) + 4 * g32;
-        L.part[(int64_t)row * NB + 32 * y + i32] = acc[0][y][r];
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 v = {acc[0][y][4 * k], acc[0][y][4 * k + 1], acc[0][y][4 * k + 2], acc[0][y][4 * k + 3]};
+        __builtin_nontemporal_store(v, (f32x4*)(prow + 32 * y + 8 * k));
       }
     }
     // lanes l and l^32 hold the two sample halves of the same neuron row (row = lane & 31)
