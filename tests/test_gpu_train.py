@@ -59,7 +59,7 @@ def train(precision, iters, n_rand=1024, seed=0, white=False, noise=1.0):
         tgt_all.append(sphere_scene(ro.reshape(-1, 3), rd.reshape(-1, 3), white))
     rays_all = torch.cat(rays_all, 1)
     tgt_all = torch.cat(tgt_all, 0)
-    g = torch.Generator(device="cpu").manual_seed(123)
+    g = torch.Generator(device="cpu").manual_seed(123 + seed)   # (its own ray batches per seed)
     psnrs = []
     for it in range(iters):
         sel = torch.randint(0, rays_all.shape[1], (n_rand,), generator=g).to(dev)
@@ -89,9 +89,10 @@ def test_bf16_training_matches_fp32_psnr():
 
     The per-step training PSNR of this scene swings by +-1.2 dB (standard deviation of a 50-step mean across seeds), so the
     comparison is made on a long window.  Measured on MI355X (tests/probes/psnr_gap.py, profiles/r02_psnr_gap.txt): 4000
-    iterations, 12 seeds, paired by seed — mean of the last 500 steps bf16 32.49 dB, fp32 32.55 dB, paired difference
-    -0.06 dB with standard error 0.07 (standard deviation of a single pair 0.25): within BASELINE.json's +-0.1 dB.  This
-    test is the one-seed, 1200-iteration version of that: the last-400-step means within 0.6 dB (> 2 sd of a pair), and
+    iterations, 12 seeds with independent batch sequences, paired by seed — mean of the last 500 steps bf16 32.97 dB, fp32
+    32.80 dB, paired difference +0.17 dB with standard error 0.12 (standard deviation of a single pair 0.42); the 500 steps
+    before: +0.02 +- 0.16: no gap at the measurement's resolution, consistent with BASELINE.json's +-0.1 dB.  This
+    test is the one-seed, 1200-iteration version of that: the last-400-step means within 0.8 dB (2 sd of a pair), and
     both paths above 24 dB."""
     iters = 1200
     p32, t32 = train("fp32", iters)
@@ -105,4 +106,4 @@ def test_bf16_training_matches_fp32_psnr():
     assert s32 > 22.0 and s16 > 22.0, "the inference path does not reproduce what was trained"
     assert tail32 > 24.0, "fp32 path did not learn the scene"
     assert tail16 > 24.0, "bf16 path did not learn the scene"
-    assert abs(tail16 - tail32) < 0.6, (tail16, tail32)
+    assert abs(tail16 - tail32) < 0.8, (tail16, tail32)
