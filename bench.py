@@ -206,8 +206,9 @@ def main():
         hargs = make_args(ns)
         hargs.lrate = 1e-2
         with contextlib.redirect_stdout(io.StringIO()):
-            hkw, _, *_ = S.create_nerf_tcnn(hargs, device=device)
+            hkw, hkw_test, *_ = S.create_nerf_tcnn(hargs, device=device)
         hkw.update(near=near, far=far)
+        hkw_test.update(near=near, far=far)
         htr = RenderTrainer(hkw, lrate=1e-2, lrate_decay=250)
         for i in range(ns.warmup):
             htr.step(H, W, focal, *batches[i % n_batches])
@@ -220,7 +221,17 @@ def main():
         hashgrid = {"workload": "same rays and sample counts, NeRF_TCNN coarse + fine (16-level 2^19 hash grid, SH4, 64-wide "
                                 "MLPs), render+mse(rgb)+mse(rgb0)+backward+dense Adam", "rays_per_s": ns.n_rand / th,
                     "ms_per_step": th * 1e3, "parity": "unpinned"}
-        del htr, hkw
+        if not ns.no_frame:
+            c2w_h = torch.eye(4)[:3, :4].to(device)
+            with torch.no_grad():
+                S.render(H, W, focal, chunk=1024 * 32, c2w=c2w_h, **hkw_test)
+                torch.cuda.synchronize()
+                tfh = time.perf_counter()
+                for _ in range(3):
+                    S.render(H, W, focal, chunk=1024 * 32, c2w=c2w_h, **hkw_test)
+                torch.cuda.synchronize()
+            hashgrid["ms_per_frame_378x504"] = (time.perf_counter() - tfh) / 3 * 1e3
+        del htr, hkw, hkw_test
 
     # BASELINE config 3 minus its unpinned LPIPS / LaMa parts: the reference's 3-render iteration (run_nerf.py:1455-1521 —
     # unmasked-pixel render, all-pixel render with detached weights, inpainted-disparity render; loss, backward, Adam)
