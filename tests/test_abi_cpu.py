@@ -175,3 +175,47 @@ def test_hashgrid_sizes_and_module_contract_on_host(S):
         S.NeRF_TCNN(hidden_dim=128)
     with pytest.raises(S.HipLibraryError):            # no CPU fallback on this path either
         net(torch.zeros(4, 6))
+
+
+def test_fused_render_rays_layout_and_argument_checks_on_host(S):
+    """snr_render_rays_fused_layout is pure host arithmetic: sections in order, 256-byte aligned, training adds the saved
+    activations and the backward workspace; bad arguments are refused before anything touches a GPU."""
+    lib = S._lib.load()
+    L = S._lib
+    cfg = L.MlpConfig(10, 4, 0, 1, 4, L.PREC_BF16)
+    blob = ctypes.c_void_p(1)    # never dereferenced by the layout query
+    net = L.Net(L.NET_MLP, cfg, blob, blob)
+    hg = L.Net(L.NET_HASHGRID, L.MlpConfig(), blob, blob)
+    rc = L.RenderConfig(64, 128, 1, 1, 1, 1.0)
+    n = 1024
+    out_i, out_t = L.RenderWsLayout(), L.RenderWsLayout()
+    assert lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(net), ctypes.byref(net), n, 0, ctypes.byref(out_i)) == 0
+    assert lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(net), ctypes.byref(net), n, 1, ctypes.byref(out_t)) == 0
+    assert out_i.z_coarse == 0 and out_i.raw0 == n * 64 * 4 and out_i.weights0 == out_i.raw0 + n * 64 * 16
+    assert out_i.z_vals > out_i.depth0 and out_i.raw == out_i.z_vals + n * 192 * 4 and out_i.d_raw == -1 and out_i.act == -1
+    for k, _ in L.RenderWsLayout._fields_:
+        v = getattr(out_t, k)
+        assert v == -1 or v % 256 == 0, k
+    act0, act = lib.snr_mlp_act_bytes(ctypes.byref(cfg), n * 64), lib.snr_mlp_act_bytes(ctypes.byref(cfg), n * 192)
+    bw = lib.snr_mlp_bwd_ws_bytes(ctypes.byref(cfg), n * 192)
+    assert out_t.total >= out_i.total + act0 + act + bw and out_t.bwd_ws + bw <= out_t.total
+    # coarse only: no fine-pass sections; hash-grid networks: their own sizes
+    rc0 = L.RenderConfig(64, 0, 0, 0, 0, 0.0)
+    o = L.RenderWsLayout()
+    assert lib.snr_render_rays_fused_layout(ctypes.byref(rc0), ctypes.byref(net), None, n, 1, ctypes.byref(o)) == 0
+    assert o.z_vals == -1 and o.raw == -1 and o.act == -1 and o.act0 > 0
+    assert lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(hg), ctypes.byref(hg), n, 1, ctypes.byref(o)) == 0
+    assert o.total > lib.snr_hashgrid_bwd_ws_bytes(n * 192)
+    # refusals
+    bad = L.Net(7, cfg, blob, blob)
+    assert lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(bad), None, n, 0, ctypes.byref(o)) == -3
+    assert lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(net), None, 0, 0, ctypes.byref(o)) == -2
+    assert lib.snr_render_rays_fused_layout(ctypes.byref(rc), None, None, n, 0, ctypes.byref(o)) == -1
+    assert lib.snr_render_rays_fused_layout(ctypes.byref(L.RenderConfig(1, 0, 0, 0, 0, 0.0)), ctypes.byref(net), None, n, 0,
+                                            ctypes.byref(o)) == -2
+    nopack = L.Net(L.NET_MLP, cfg, None, blob)
+    assert lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(nopack), None, n, 0, ctypes.byref(o)) == -1
+    assert lib.snr_render_rays_fused_forward(ctypes.byref(rc), ctypes.byref(net), None, None, 11, n, None, None, None, None, 0, 0,
+                                             None, n, None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.snr_render_rays_fused_backward(ctypes.byref(rc), ctypes.byref(net), None, blob, 11, n, blob, blob, None, 0, 0,
+                                              None) == -2       # no pass selected
