@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _setup():
+def _setup(kind="mlp"):
     import importlib
     import numpy as np
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -24,8 +24,15 @@ def _setup():
     Nc, Nf, N = 64, 32, 48       # N = global batch, split in two
     nets = []
     for seed in (3, 4):
-        n = S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True, precision="fp32").cuda()
-        n.load_state_dict(O.init_nerf_params(seed=seed))
+        if kind == "hash":      # the reference's default networks (create_nerf_tcnn): one flat [table | MLPs] buffer each
+            from oracle import hashgrid_oracle as HG
+            sd = HG.init_params(seed)
+            sd["encoder.params"] = sd["encoder.params"] * 3e3
+            n = S.NeRF_TCNN().cuda()
+            n.load_state_dict(sd)
+        else:
+            n = S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True, precision="fp32").cuda()
+            n.load_state_dict(O.init_nerf_params(seed=seed))
         nets.append(n)
 
     def q(inputs, viewdirs, network_fn):
@@ -44,12 +51,12 @@ def _setup():
     return train, kw, nets, (H, W, focal), rays, target, rnd
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, kind):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    train, kw, nets, hwf, rays, target, rnd = _setup()
+    train, kw, nets, hwf, rays, target, rnd = _setup(kind)
     tr = train.RenderTrainer(kw, lrate=5e-4, world_size=world)
     tr.broadcast_parameters()
     n = rays.shape[1] // world
@@ -65,23 +72,25 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_step_equals_single_process_step_on_the_global_batch(tmp_path):
+@pytest.mark.parametrize("kind", ["mlp", "hash"])
+def test_two_rank_step_equals_single_process_step_on_the_global_batch(tmp_path, kind):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "rank0.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, kind), nprocs=2, join=True)
     r0, r1 = torch.load(out), torch.load(out + ".1")
     # single process, whole batch
-    train, kw, nets, hwf, rays, target, rnd = _setup()
+    train, kw, nets, hwf, rays, target, rnd = _setup(kind)
     tr = train.RenderTrainer(kw, lrate=5e-4)
     tr.step(*hwf, rays.cuda(), target.cuda(), randoms={k: v.cuda() for k, v in rnd.items()})
     for i, net in enumerate(nets):
         g1 = net.flat.grad.cpu().double()
         g2 = r0["grad_sum"][i].double() / 2        # the trainer folds 1 / world into the Adam kernel
         rel = float((g1 - g2).norm() / g1.norm())
-        assert rel < 1e-5, f"net {i}: reduced gradient differs from the single-process gradient by {rel:.2e}"
+        # (hash networks: bf16 kernels, and the table gradient is summed by atomics in a different order)
+        assert rel < (1e-5 if kind == "mlp" else 2e-3), f"net {i}: reduced gradient differs from the single-process gradient by {rel:.2e}"
         assert torch.equal(r0["params"][i], r1["params"][i]), "replicas diverged"
         # (parameters vs the single-process step: equal up to elements whose gradient rounds to the other sign — Adam moves
         #  every element by lr whatever the gradient's size, see tests/test_gpu_train_step.py)
         d = (r0["params"][i] - net.flat.detach().cpu()).abs()
-        assert float((d > 1e-7).float().mean()) < 2e-3
+        assert float((d > 1e-7).float().mean()) < (2e-3 if kind == "mlp" else 0.2)
