@@ -460,7 +460,8 @@ def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bk
                   target, loss, n_rays_global=None, randoms=None):
     """render_rays + the loss terms + the compositing backward of one training step in one library call.  ``net_f`` None
     with N_importance > 0 = the coarse network evaluated twice.  Consumes the Philox offsets offset+1 .. offset+4.
-    Returns a FusedRender; fused_backward(handle) gives the parameter gradients."""
+    Returns a FusedRender; fused_backward(handle) gives the parameter gradients.  ``target`` None (and ``loss`` None) =
+    inference: forward only, nothing saved for a backward."""
     import ctypes
     lib = _lib.load()
     rnd = randoms or {}
@@ -472,7 +473,7 @@ def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bk
     sf, pf = _net_struct(net_f) if two else (None, None)
     L = _lib.RenderWsLayout()
     fptr = ctypes.byref(sf) if two else None
-    check(lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(sc), fptr, n, 1, ctypes.byref(L)),
+    check(lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(sc), fptr, n, int(target is not None), ctypes.byref(L)),
           "snr_render_rays_fused_layout")
     dev = rays.device
     ws = torch.empty(L.total, device=dev, dtype=torch.uint8)

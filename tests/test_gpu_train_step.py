@@ -199,3 +199,29 @@ def test_fused_library_step_equals_the_per_kernel_step(monkeypatch, Nf):
             continue
         assert torch.equal(na.flat.grad, nb.flat.grad)
         assert torch.equal(na.flat.detach(), nb.flat.detach())
+
+
+@pytest.mark.parametrize("Nf", [128, 0])
+def test_fused_forward_in_inference_mode_equals_render(Nf):
+    """snr_render_rays_fused_forward without a target is render_rays' forward alone: its maps and the dict tensors it keeps
+    in the workspace (weights, z_vals, raw, z_std) must be what render() returns for the same rays (perturb = 0, no
+    density noise), bit for bit — both routes issue the same kernels."""
+    import spin_nerf_amd as S
+    (a, _), hwf, rays, target, _ = _two_trainers("bf16", Nf)
+    tr, nets = a
+    kw = dict(tr.kw); kw.update(perturb=0., raw_noise_std=0.)
+    with torch.no_grad():
+        rgb, disp, acc, depth, ex = S.render(*hwf, rays=rays, retraw=True, **kw)
+    rows = S.ops.pack_rays(rays[0], rays[1], *hwf, ndc=False, near=kw["near"], far=kw["far"], use_viewdirs=True)
+    h = S.ops.fused_forward(nets[0], nets[1] if Nf else None, rows, 64, Nf, True, True, 0., 0., seed=1, offset=0, target=None, loss=None)
+    n, S_ = rows.shape[0], 64 + Nf
+    assert torch.equal(h.rgb, rgb) and torch.equal(h.disp, disp) and torch.equal(h.acc, acc) and torch.equal(h.depth, depth)
+    if Nf:
+        assert torch.equal(h.rgb0, ex["rgb0"]) and torch.equal(h.disp0, ex["disp0"]) and torch.equal(h.acc0, ex["acc0"])
+        assert torch.equal(h.z_std, ex["z_std"])
+        assert torch.equal(h.view("z_vals", n, S_), ex["z_vals"]) and torch.equal(h.view("weights", n, S_), ex["weights"])
+        assert torch.equal(h.view("raw", n, S_, 4), ex["raw"])
+    else:
+        assert torch.equal(h.view("z_coarse", n, 64), ex["z_vals"]) and torch.equal(h.view("weights0", n, 64), ex["weights"])
+        assert torch.equal(h.view("raw0", n, 64, 4), ex["raw"])
+    assert h.layout.act0 == -1 and h.layout.d_raw0 == -1
