@@ -336,6 +336,120 @@ __global__ __launch_bounds__(256) void composite_train_kernel(
   }
 }
 
+// The same kernel with the ray held in registers (S <= 64 * NCH): every global load of the ray is issued up front, the
+// forward, the loss gradient and the backward then run out of registers.  The generic version above walks the ray three
+// times (forward, the backward's accumulate pass, the backward's reverse pass with its prefix recomputation), each chunk
+// waiting for its own loads — with one wave per SIMD that latency chain was the kernel (16.5 us for 1024 rays x 192
+// samples).  Arithmetic and its order are those of composite_fwd_ray / composite_bwd_ray with g_disp = g_acc = g_depth = 0.
+template <int NCH>
+__global__ __launch_bounds__(256) void composite_train_reg_kernel(
+    const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
+    NoiseSrc ns, int64_t n_rays, int S, int white, int detach, const float* __restrict__ target, float inv_count,
+    float* __restrict__ rgb_map, float* __restrict__ disp_map, float* __restrict__ acc_map,
+    float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, float* __restrict__ loss,
+    float* __restrict__ loss_also) {
+  __shared__ float sq[kRaysPerBlock];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+  float e2 = 0.f;
+  if (ray < n_rays) {
+    const float* rd = rays + ray * ld + 3;
+    const float* zr = z_vals + ray * S;
+    float z[NCH], zn[NCH], r0[NCH], r1[NCH], r2[NCH], s[NCH];
+    bool in[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {          // all loads of the ray, independent of each other
+      const int i = 64 * c + lane;
+      in[c] = i < S;
+      z[c] = zn[c] = r0[c] = r1[c] = r2[c] = s[c] = 0.f;
+      if (in[c]) {
+        z[c] = zr[i];
+        zn[c] = (i + 1 < S) ? zr[i + 1] : 0.f;
+        const float* rw = raw + (ray * S + i) * C;
+        if (C == 4) {
+          const f32x4 v = *(const f32x4*)rw;
+          r0[c] = v[0]; r1[c] = v[1]; r2[c] = v[2]; s[c] = v[3];
+        } else {
+          r0[c] = rw[0]; r1[c] = rw[1]; r2[c] = rw[2]; s[c] = rw[3];
+        }
+      }
+    }
+    const float t0 = target[3 * ray], t1 = target[3 * ray + 1], t2 = target[3 * ray + 2];
+    const float dn = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
+    // ---- forward (composite_fwd_ray) ----
+    float dist[NCH], c0[NCH], c1[NCH], c2[NCH], one_m[NCH], Ti[NCH], w[NCH];
+    float T = 1.f, sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int i = 64 * c + lane;
+      float a = 0.f;
+      dist[c] = 0.f; c0[c] = c1[c] = c2[c] = 0.f; one_m[c] = 1.f;
+      if (in[c]) {
+        float d = (i + 1 < S) ? (zn[c] - z[c]) : 1e10f;
+        dist[c] = d * dn;
+        c0[c] = sigmoidf(r0[c]); c1[c] = sigmoidf(r1[c]); c2[c] = sigmoidf(r2[c]);
+        s[c] = s[c] + noise_at(ns, ray * S + i);
+        a = 1.f - expf(-relu_nan(s[c]) * dist[c]);
+        one_m[c] = 1.f - a + 1e-10f;
+      }
+      const float incl = wave_incl_scan_mul(one_m[c], lane);
+      float excl = __shfl_up(incl, 1, kWave);
+      if (lane == 0) excl = 1.f;
+      Ti[c] = T * excl;
+      w[c] = a * Ti[c];
+      T = T * __shfl(incl, kWave - 1, kWave);
+      if (in[c]) weights[ray * S + i] = w[c];
+      sr += w[c] * c0[c]; sg += w[c] * c1[c]; sb += w[c] * c2[c]; sd += w[c] * z[c]; sa += w[c];
+    }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+    const float q = sd / sa;
+    const float disp = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
+    if (white) { sr += 1.f - sa; sg += 1.f - sa; sb += 1.f - sa; }
+    if (lane == 0) {
+      rgb_map[3 * ray] = sr; rgb_map[3 * ray + 1] = sg; rgb_map[3 * ray + 2] = sb;
+      disp_map[ray] = disp; acc_map[ray] = sa; depth_map[ray] = sd;
+    }
+    // ---- loss gradient and backward (composite_bwd_ray with g_disp = g_acc = g_depth = 0) ----
+    const float dr = sr - t0, dg = sg - t1, db = sb - t2;
+    e2 = dr * dr + dg * dg + db * db;
+    const float gr = 2.f * dr * inv_count, gg = 2.f * dg * inv_count, gb = 2.f * db * inv_count;
+    const float gwhite = white ? -(gr + gg + gb) : 0.f;
+    float suffix_next = 0.f;
+#pragma unroll
+    for (int c = NCH - 1; c >= 0; --c) {
+      const int i = 64 * c + lane;
+      float G = 0.f * z[c] + 0.f + gwhite + 0.f;
+      if (!detach) G += gr * c0[c] + gg * c1[c] + gb * c2[c];
+      if (!in[c]) G = 0.f;
+      const float Gw = G * w[c];
+      const float suf_incl = wave_suffix_scan_add(Gw, lane);
+      const float suf_excl = suf_incl - Gw + suffix_next;
+      suffix_next += __shfl(suf_incl, 0, kWave);
+      if (in[c]) {
+        const float dalpha = G * Ti[c] - suf_excl / one_m[c];
+        const float ds = (s[c] > 0.f) ? dalpha * dist[c] * expf(-s[c] * dist[c]) : 0.f;
+        float* o = d_raw + (ray * S + i) * C;
+        const float o0 = gr * w[c] * c0[c] * (1.f - c0[c]), o1 = gg * w[c] * c1[c] * (1.f - c1[c]),
+                    o2 = gb * w[c] * c2[c] * (1.f - c2[c]);
+        if (C == 4) {
+          *(f32x4*)o = f32x4{o0, o1, o2, ds};
+        } else {
+          o[0] = o0; o[1] = o1; o[2] = o2; o[3] = ds;
+          for (int k = 4; k < C; ++k) o[k] = 0.f;
+        }
+      }
+    }
+  }
+  if (lane == 0) sq[wv] = e2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < kRaysPerBlock; ++k) t += sq[k];
+    atomicAdd(loss, t * inv_count);
+    if (loss_also) atomicAdd(loss_also, t * inv_count);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // hierarchical sampling (helpers:304-347) + sort of the union (run_nerf.py:702) + z_std (:726)
 // one wave per ray; LDS per wave: cdf[Nc-1], bins[Nc-1], sort buffer[pow2 >= Nc+Nf]
@@ -770,9 +884,18 @@ extern "C" int snr_composite_train(const float* raw, int C, const float* z, cons
   const NoiseSrc ns{noise, (!noise && noise_std > 0.f) ? 1 : 0, make_rng(seed, offset), noise_std};
   {
     ProfScope ps(K_COMPOSITE_FWD, (hipStream_t)stream);
-    composite_train_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(
-        raw, C, z, rays, ld, ns, n_rays, S, white, detach, target, 1.f / (3.f * (float)n_rays_global), rgb_map, disp_map,
-        acc_map, depth_map, weights, d_raw, loss, loss_also);
+    const float inv_count = 1.f / (3.f * (float)n_rays_global);
+    const int nch = (S + kWave - 1) / kWave;
+#define SNR_CT_ARGS raw, C, z, rays, ld, ns, n_rays, S, white, detach, target, inv_count, rgb_map, disp_map, acc_map, depth_map, \
+                    weights, d_raw, loss, loss_also
+    // 16-byte raw rows (C == 4) need 16-byte aligned bases for the vector accesses of the register-resident version
+    const bool aligned = C != 4 || ((((uintptr_t)raw) | ((uintptr_t)d_raw)) & 15) == 0;
+    if (nch == 1 && aligned) composite_train_reg_kernel<1><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(SNR_CT_ARGS);
+    else if (nch == 2 && aligned) composite_train_reg_kernel<2><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(SNR_CT_ARGS);
+    else if (nch == 3 && aligned) composite_train_reg_kernel<3><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(SNR_CT_ARGS);
+    else if (nch == 4 && aligned) composite_train_reg_kernel<4><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(SNR_CT_ARGS);
+    else composite_train_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(SNR_CT_ARGS);
+#undef SNR_CT_ARGS
   }
   return launch_status();
 }
