@@ -41,7 +41,7 @@ template <int P> __device__ __forceinline__ int act_row(int j, int f) {
 #define SNR_ABLATE 0   // bit mask of timing experiments (results are garbage): see Pipe
 #endif
 // kBlockFrags (mlp_layout.h) fragments per block; ring slots and blocks in flight are chosen so that the bytes in
-// flight stay 64 KiB: 16-fragment blocks -> 6 slots, 4 ahead; 32-fragment blocks (A/B builds) -> 4 slots, 2 ahead
+// flight stay 64 KiB: 32-fragment blocks -> 4 slots, 2 ahead (128 KiB of LDS); 16-fragment blocks (A/B builds) -> 6 slots, 4 ahead
 constexpr int kRing = kBlockFrags == 16 ? 6 : 4;
 constexpr int kDepth = kRing - 2;    // the slot re-filled on entering block b is that of block b-2
 constexpr int kRingBytes = kRing * kBlockFrags * 1024;

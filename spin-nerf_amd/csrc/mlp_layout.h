@@ -43,7 +43,8 @@ enum Precision { kBF16 = 0, kFP32 = 1 };
 
 // fragments (1 KiB each) per DMA block of the packed weight stream; every stage starts on a block boundary
 #ifndef SNR_BLOCK_FRAGS
-#define SNR_BLOCK_FRAGS 16   // A/B builds: 32
+#define SNR_BLOCK_FRAGS 32   // 32 KiB blocks: half the block entries (counted wait + barrier) of 16; same-call A/B:
+                             // training forward -2.5 %, inference frame -1.8 %, dgrad unchanged (A/B builds: 16)
 #endif
 constexpr int kBlockFrags = SNR_BLOCK_FRAGS;
 
