@@ -60,7 +60,9 @@ template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4;
 //    (which looked like "each LDS-DMA instruction blocks its wave ~170 cycles") and 4 waves x 2 tiles was the
 //    best training shape (0.373 / 0.286 ms forward / dgrad vs 0.384 / 0.331 at 4 x 1); with the asm reads
 //    4 x 2 runs out of registers (139 spilled dwords) and 8 x 1 with packed epilogues is 0.33 / 0.28 ms;
-//    inference 8 x 1: 0.21 ms = 1100 TFLOP/s (4 x 2: 113 spilled dwords, 0.281 ms).
+//    inference 8 x 1: 0.21 ms = 1100 TFLOP/s (4 x 2: 113 spilled dwords, 0.281 ms).  Round 2, after the encoding's
+//    loop invariants stopped occupying registers: 4 x 2 (512 registers, 27 spilled dwords) renders a frame in the
+//    same 59.7 ms as 8 x 1 — halving the LDS fragment reads buys nothing, as tests/probes/mfma_feed.hip predicts.
 //  * fp32 (parity path): 4 waves x 1 tile — its activations alone are 256 registers.
 template <int P, bool TRAIN> struct ChainCfg { static constexpr int WAVES = 4, NJ = 1; };
 #if defined(SNR_INFER_WAVES) && defined(SNR_INFER_NJ)   // A/B builds only
