@@ -175,6 +175,8 @@ def main():
     rays_per_s = world * ns.n_rand * ns.steps / elapsed
 
     # ---- per-kernel timing with HIP events on the launch stream: the same K steps again, profiled ----
+    graph_route = bool(getattr(trainer, "_graph", None))
+    trainer._graph_on = False          # per-kernel events need real launches: the profiled repeat runs eagerly
     S._lib.prof_enable(True)
     S._lib.prof_read()
     torch.cuda.synchronize()
@@ -184,6 +186,7 @@ def main():
     prof_elapsed = time.perf_counter() - tp0
     prof = S._lib.prof_read()
     S._lib.prof_enable(False)
+    trainer._graph_on = graph_route
 
     # ---- ms/frame: full 378x504 frame, no_grad, perturb=0, raw_noise_std=0 ----
     ms_frame = None
@@ -329,6 +332,7 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
         "ms_per_step_profiled": prof_elapsed / ns.steps * 1e3,
+        "step_route": "captured HIP graph replay (SNR_STEP_GRAPH=1)" if graph_route else "two fused library calls + Adam per step",
     }
     if hashgrid is not None:
         out["also_measured"] = {"hashgrid_config5": hashgrid}

@@ -183,6 +183,25 @@ int snr_composite_train(const float* raw, int raw_ch, const float* z_vals, const
                         float* disp_map, float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss,
                         float* loss_also, snr_stream_t stream);
 
+/* ---- per-step scalars in DEVICE memory, so that a captured HIP graph of the training step can be replayed: the draw
+ * counter the in-kernel random numbers are offset by, and Adam's rate / bias corrections (run_nerf.py:1611-1622).  The
+ * struct describes the step about to run; snr_step_state_advance turns it into the next one on the device exactly as
+ * the host would (lr = lrate * 0.1^(global_step / decay_steps) from the not yet incremented global_step). ---- */
+typedef struct snr_step_state {
+  uint64_t offset_base;  /* added to every call offset of this step's draws */
+  int64_t opt_step;      /* Adam's step number of this step (1-based) */
+  int64_t global_step;   /* completed optimisation steps */
+  float lr;              /* rate this step uses */
+  float bc1;             /* 1 - beta1^opt_step */
+  float bc2_sqrt;        /* sqrt(1 - beta2^opt_step) */
+  float reserved;
+} snr_step_state;
+int snr_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const snr_step_state* state, float beta1, float beta2, float eps, float grad_scale,
+                      snr_stream_t stream);
+int snr_step_state_advance(snr_step_state* state, double lrate, double decay_steps, float beta1, float beta2,
+                           uint64_t n_offsets, snr_stream_t stream);
+
 /* ---- render_rays as ONE call (render_rays_fused_forward / _backward): the launch sequence of
  * run_nerf.py:593-737 — stratified sampling, coarse network, compositing, hierarchical sampling + sort, fine network,
  * compositing — enqueued by the library on `stream`, every intermediate in one caller-provided workspace; with `target`
@@ -218,7 +237,8 @@ int snr_render_rays_fused_layout(const snr_render_config* cfg, const snr_net* co
                                  int train, snr_render_ws_layout* out);
 /* rays: packed rows (snr_pack_rays / snr_make_rays).  Random draws: t_rand [n,Nc], u [n,Nf], noise0 [n,Nc], noise
  * [n,Nc+Nf] (pre-scaled) when non-NULL, else Philox draws with offsets offset+1 (t_rand), +2 (noise0), +3 (u), +4 (noise)
- * under `seed` when the configuration asks for random numbers (the call always consumes four offsets).
+ * under `seed` when the configuration asks for random numbers (the call always consumes four offsets); offset_base
+ * (device memory, may be NULL) is added to them at run time — snr_step_state.offset_base of a captured step.
  * target [n,3] non-NULL = training: loss[0] += mse(rgb, target) + mse(rgb0, target) terms over 3 * n_rays_global
  * elements, loss[1] += the final map's term alone (zero both first); the workspace then holds what the backward needs.
  * Outputs (all required): rgb/disp/acc/depth maps of the final pass, rgb0/disp0/acc0 of the coarse pass and z_std [n]
@@ -226,7 +246,7 @@ int snr_render_rays_fused_layout(const snr_render_config* cfg, const snr_net* co
 int snr_render_rays_fused_forward(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine,
                                   const float* rays, int ray_ld, int64_t n_rays, const float* t_rand, const float* u,
                                   const float* noise0, const float* noise, uint64_t seed, uint64_t offset,
-                                  const float* target, int64_t n_rays_global, void* ws, float* rgb_map, float* disp_map,
+                                  const uint64_t* offset_base, const float* target, int64_t n_rays_global, void* ws, float* rgb_map, float* disp_map,
                                   float* acc_map, float* depth_map, float* rgb0, float* disp0, float* acc0, float* z_std,
                                   float* loss, snr_stream_t stream);
 /* parameter gradients of the training forward above (same cfg / networks / rays / ws): grad_coarse and grad_fine (flat

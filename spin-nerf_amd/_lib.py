@@ -48,6 +48,11 @@ class RenderWsLayout(_c.Structure):  # snr_render_ws_layout
                                   "d_raw", "act0", "act", "bwd_ws", "total")]
 
 
+class StepState(_c.Structure):      # snr_step_state
+    _fields_ = [("offset_base", _c.c_uint64), ("opt_step", _l), ("global_step", _l), ("lr", _f), ("bc1", _f),
+                ("bc2_sqrt", _f), ("reserved", _f)]
+
+
 _NET, _RCFG = _c.POINTER(Net), _c.POINTER(RenderConfig)
 
 # name -> (restype, argtypes); mirrors include/spinnerf_hip.h one to one
@@ -80,8 +85,10 @@ SIGNATURES = {
     "snr_composite_train": (_i, [_p, _i, _p, _p, _i, _p, _f, _c.c_uint64, _c.c_uint64, _l, _i, _i, _i, _p, _l, _p, _p, _p, _p,
                                  _p, _p, _p, _p, _p]),
     "snr_render_rays_fused_layout": (_i, [_RCFG, _NET, _NET, _l, _i, _c.POINTER(RenderWsLayout)]),
-    "snr_render_rays_fused_forward": (_i, [_RCFG, _NET, _NET, _p, _i, _l, _p, _p, _p, _p, _c.c_uint64, _c.c_uint64, _p, _l, _p,
-                                           _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "snr_adam_step_dev": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _p]),
+    "snr_step_state_advance": (_i, [_p, _c.c_double, _c.c_double, _f, _f, _c.c_uint64, _p]),
+    "snr_render_rays_fused_forward": (_i, [_RCFG, _NET, _NET, _p, _i, _l, _p, _p, _p, _p, _c.c_uint64, _c.c_uint64, _p, _p, _l,
+                                           _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "snr_render_rays_fused_backward": (_i, [_RCFG, _NET, _NET, _p, _i, _l, _p, _p, _p, _i, _i, _p]),
     "snr_make_rays": (_i, [_i, _i, _f, _c.POINTER(_f), _i, _i, _i, _i, _i, _f, _f, _i, _p, _i, _p]),
     "snr_sample_pdf": (_i, [_p, _p, _p, _l, _i, _i, _p, _p]),

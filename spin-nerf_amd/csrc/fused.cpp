@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "../../include/spinnerf_hip.h"
+#include "render_internal.h"
 
 namespace {
 
@@ -95,7 +96,7 @@ extern "C" int snr_render_rays_fused_layout(const snr_render_config* cfg, const 
 extern "C" int snr_render_rays_fused_forward(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine,
                                              const float* rays, int ray_ld, int64_t n_rays, const float* t_rand,
                                              const float* u, const float* noise0, const float* noise, uint64_t seed,
-                                             uint64_t offset, const float* target, int64_t n_rays_global, void* ws,
+                                             uint64_t offset, const uint64_t* offset_base, const float* target, int64_t n_rays_global, void* ws,
                                              float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* rgb0,
                                              float* disp0, float* acc0, float* z_std, float* loss, snr_stream_t stream) {
   snr_render_ws_layout L;
@@ -114,7 +115,7 @@ extern "C" int snr_render_rays_fused_forward(const snr_render_config* cfg, const
   const int last0 = Nf == 0;   // the coarse pass is the final one
 
   // ---- coarse pass (run_nerf.py:646-692) ----
-  if (cfg->perturb && !t_rand) st = snr_sample_coarse_rng(rays, ray_ld, n_rays, Nc, cfg->lindisp, seed, offset + 1, F(L.z_coarse), stream);
+  if (cfg->perturb && !t_rand) st = snr::sample_coarse_rng_impl(rays, ray_ld, n_rays, Nc, cfg->lindisp, seed, offset + 1, offset_base, F(L.z_coarse), stream);
   else st = snr_sample_coarse(rays, ray_ld, n_rays, Nc, cfg->lindisp, cfg->perturb ? t_rand : nullptr, F(L.z_coarse), stream);
   if (st != SNR_OK) return st;
   st = net_forward(coarse, rays, ray_ld, F(L.z_coarse), n_rays, Nc, F(L.raw0), train ? w + L.act0 : nullptr, stream);
@@ -124,8 +125,8 @@ extern "C" int snr_render_rays_fused_forward(const snr_render_config* cfg, const
   float* m_acc = last0 ? acc_map : acc0;
   float* m_depth = last0 ? depth_map : F(L.depth0);
   if (train) {
-    st = snr_composite_train(F(L.raw0), C0, F(L.z_coarse), rays, ray_ld, noise0, cfg->raw_noise_std, seed, offset + 2, n_rays,
-                             Nc, cfg->white_bkgd, 0, target, n_rays_global, m_rgb, m_disp, m_acc, m_depth, F(L.weights0),
+    st = snr::composite_train_impl(F(L.raw0), C0, F(L.z_coarse), rays, ray_ld, noise0, cfg->raw_noise_std, seed, offset + 2,
+                                   offset_base, n_rays, Nc, cfg->white_bkgd, 0, target, n_rays_global, m_rgb, m_disp, m_acc, m_depth, F(L.weights0),
                              F(L.d_raw0), loss, last0 ? loss + 1 : nullptr, stream);
   } else {
     if (cfg->raw_noise_std > 0.f && !noise0) return SNR_ERR_UNSUPPORTED;   // inference renders without density noise
@@ -135,13 +136,14 @@ extern "C" int snr_render_rays_fused_forward(const snr_render_config* cfg, const
   if (st != SNR_OK || last0) return st;
 
   // ---- hierarchical sampling + fine pass (run_nerf.py:694-713) ----
-  if (cfg->perturb && !u) st = snr_sample_fine_rng(F(L.z_coarse), F(L.weights0), n_rays, Nc, Nf, seed, offset + 3, F(L.z_vals), F(L.z_samples), z_std, stream);
+  if (cfg->perturb && !u) st = snr::sample_fine_rng_impl(F(L.z_coarse), F(L.weights0), n_rays, Nc, Nf, seed, offset + 3, offset_base, F(L.z_vals), F(L.z_samples), z_std, stream);
   else st = snr_sample_fine(F(L.z_coarse), F(L.weights0), cfg->perturb ? u : nullptr, n_rays, Nc, Nf, F(L.z_vals), F(L.z_samples), z_std, stream);
   if (st != SNR_OK) return st;
   st = net_forward(f, rays, ray_ld, F(L.z_vals), n_rays, S, F(L.raw), train ? w + L.act : nullptr, stream);
   if (st != SNR_OK) return st;
   if (train)
-    return snr_composite_train(F(L.raw), C1, F(L.z_vals), rays, ray_ld, noise, cfg->raw_noise_std, seed, offset + 4, n_rays, S,
+    return snr::composite_train_impl(F(L.raw), C1, F(L.z_vals), rays, ray_ld, noise, cfg->raw_noise_std, seed, offset + 4, offset_base,
+                                     n_rays, S,
                                cfg->white_bkgd, 0, target, n_rays_global, rgb_map, disp_map, acc_map, depth_map, F(L.weights),
                                F(L.d_raw), loss, loss + 1, stream);
   if (cfg->raw_noise_std > 0.f && !noise) return SNR_ERR_UNSUPPORTED;

@@ -1,0 +1,19 @@
+// Internal (not part of the C ABI): the in-kernel-draw entry points with the optional device-side offset base that
+// snr_render_rays_fused_forward passes through (include/spinnerf_hip.h: snr_step_state).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/spinnerf_hip.h"
+
+namespace snr {
+int sample_coarse_rng_impl(const float* rays, int ld, int64_t n_rays, int N, int lindisp, uint64_t seed, uint64_t offset,
+                           const uint64_t* base, float* z_vals, snr_stream_t stream);
+int sample_fine_rng_impl(const float* z_coarse, const float* weights, int64_t n_rays, int Nc, int Nf, uint64_t seed,
+                         uint64_t offset, const uint64_t* base, float* z_out, float* z_samples, float* z_std,
+                         snr_stream_t stream);
+int composite_train_impl(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
+                         float noise_std, uint64_t seed, uint64_t offset, const uint64_t* base, int64_t n_rays, int S,
+                         int white, int detach, const float* target, int64_t n_rays_global, float* rgb_map, float* disp_map,
+                         float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss, float* loss_also,
+                         snr_stream_t stream);
+}  // namespace snr

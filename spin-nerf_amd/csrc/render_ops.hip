@@ -6,6 +6,7 @@
 // for the binary search table and the bitonic merge.  Compiled with -ffp-contract=off so the
 // elementwise arithmetic rounds like the reference's separate torch ops.
 #include "snr_common.h"
+#include "render_internal.h"
 
 namespace snr {
 
@@ -56,7 +57,14 @@ __device__ __forceinline__ float linspace01(int i, int n) {
 // call = counter (i, 0, offset_lo, offset_hi) under key (seed_lo, seed_hi) — no state, no generator launch, and a
 // backward pass re-derives the forward's noise from the same (seed, offset) instead of reading it back from HBM.
 // ------------------------------------------------------------------------------------------
-struct Rng { uint32_t seed_lo, seed_hi, off_lo, off_hi; };
+// `base`: optional device counter added to the call offset — lets a captured HIP graph replay the same launch with
+// fresh draws (the counter is advanced on the device, snr_step_state_advance)
+struct Rng { uint32_t seed_lo, seed_hi, off_lo, off_hi; const unsigned long long* base; };
+__device__ __forceinline__ void rng_offset(const Rng& g, uint32_t& lo, uint32_t& hi) {
+  unsigned long long off = ((unsigned long long)g.off_hi << 32) | g.off_lo;
+  if (g.base) off += *g.base;
+  lo = (uint32_t)off; hi = (uint32_t)(off >> 32);
+}
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -70,13 +78,17 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 }
 // U[0, 1) with 24 random bits (torch.rand's range)
 __device__ __forceinline__ float rng_uniform(const Rng& g, int64_t i) {
-  uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), g.off_lo, g.off_hi};
+  uint32_t olo, ohi;
+  rng_offset(g, olo, ohi);
+  uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), olo, ohi};
   philox4x32_10(c, g.seed_lo, g.seed_hi);
   return (float)(c[0] >> 8) * 5.9604644775390625e-8f;
 }
 // N(0, 1): Box-Muller on two words of one block
 __device__ __forceinline__ float rng_normal(const Rng& g, int64_t i) {
-  uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), g.off_lo, g.off_hi};
+  uint32_t olo, ohi;
+  rng_offset(g, olo, ohi);
+  uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), olo, ohi};
   philox4x32_10(c, g.seed_lo, g.seed_hi);
   const float u1 = (float)((c[0] >> 8) + 1u) * 5.9604644775390625e-8f;   // (0, 1]
   const float u2 = (float)(c[1] >> 8) * 5.9604644775390625e-8f;
@@ -688,6 +700,48 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// beta^k by squaring, in double: the same sequence of IEEE multiplications on the host (snr_adam_step) and on the device
+// (step_state_advance_kernel), so that a replayed graph and the eager step use bit-identical bias corrections — libm's
+// and the device library's pow() differ in the last bit now and then, and one ulp in a parameter is enough for bf16
+// rounding + Adam to send two runs apart
+__host__ __device__ inline double powi(double b, long long k) {
+  double r = 1.0;
+  while (k > 0) {
+    if (k & 1) r *= b;
+    b *= b;
+    k >>= 1;
+  }
+  return r;
+}
+
+// Adam with the step's rate and bias corrections read from device memory (snr_step_state), for captured graphs
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, int64_t n, const snr_step_state* __restrict__ st, float b1, float b2,
+                                float eps, float gscale) {
+  const float lr = st->lr, bc1 = st->bc1, bc2_sqrt = st->bc2_sqrt;
+  const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  for (int64_t i = i0; i < n && i < i0 + 4; ++i) {
+    const float gk = g[i] * gscale;
+    const float mk = m[i] * b1 + (1.f - b1) * gk;
+    const float vk = v[i] * b2 + (1.f - b2) * gk * gk;
+    const float denom = sqrtf(vk) / bc2_sqrt + eps;
+    m[i] = mk; v[i] = vk;
+    p[i] = p[i] - (lr / bc1) * (mk / denom);
+  }
+}
+
+// what RenderTrainer.apply_gradients does on the host after a step (run_nerf.py:1616-1622, 1703), on the device
+__global__ void step_state_advance_kernel(snr_step_state* st, double lrate, double decay_steps, double b1, double b2,
+                                          unsigned long long n_offsets) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->offset_base += n_offsets;
+  st->lr = (float)(lrate * pow(0.1, (double)st->global_step / decay_steps));
+  st->global_step += 1;
+  st->opt_step += 1;
+  st->bc1 = (float)(1.0 - powi(b1, st->opt_step));
+  st->bc2_sqrt = (float)sqrt(1.0 - powi(b2, st->opt_step));
+}
+
 }  // namespace snr
 
 using namespace snr;
@@ -831,26 +885,31 @@ extern "C" int snr_composite_alpha_backward(const float* raw, int C, const float
   return launch_status();
 }
 
-static Rng make_rng(uint64_t seed, uint64_t offset) {
-  return Rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+static Rng make_rng(uint64_t seed, uint64_t offset, const uint64_t* base = nullptr) {
+  return Rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset, (uint32_t)(offset >> 32),
+             (const unsigned long long*)base};
 }
 
-extern "C" int snr_sample_coarse_rng(const float* rays, int ld, int64_t n_rays, int N, int lindisp, uint64_t seed,
-                                     uint64_t offset, float* z_vals, snr_stream_t stream) {
+int snr::sample_coarse_rng_impl(const float* rays, int ld, int64_t n_rays, int N, int lindisp, uint64_t seed, uint64_t offset,
+                                const uint64_t* base, float* z_vals, snr_stream_t stream) {
   SNR_CHECK_ARG(rays && z_vals, SNR_ERR_NULL);
   SNR_CHECK_ARG(n_rays > 0 && N > 0 && ld >= 8, SNR_ERR_SHAPE);
   const int64_t n = n_rays * N;
   {
     ProfScope ps(K_SAMPLE_COARSE, (hipStream_t)stream);
     sample_coarse_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        rays, ld, n_rays, N, lindisp, nullptr, 1, make_rng(seed, offset), z_vals);
+        rays, ld, n_rays, N, lindisp, nullptr, 1, make_rng(seed, offset, base), z_vals);
   }
   return launch_status();
 }
+extern "C" int snr_sample_coarse_rng(const float* rays, int ld, int64_t n_rays, int N, int lindisp, uint64_t seed,
+                                     uint64_t offset, float* z_vals, snr_stream_t stream) {
+  return snr::sample_coarse_rng_impl(rays, ld, n_rays, N, lindisp, seed, offset, nullptr, z_vals, stream);
+}
 
-extern "C" int snr_sample_fine_rng(const float* z_coarse, const float* weights, int64_t n_rays, int Nc, int Nf,
-                                   uint64_t seed, uint64_t offset, float* z_out, float* z_samples, float* z_std,
-                                   snr_stream_t stream) {
+int snr::sample_fine_rng_impl(const float* z_coarse, const float* weights, int64_t n_rays, int Nc, int Nf, uint64_t seed,
+                              uint64_t offset, const uint64_t* base, float* z_out, float* z_samples, float* z_std,
+                              snr_stream_t stream) {
   SNR_CHECK_ARG(z_coarse && weights && z_out, SNR_ERR_NULL);
   SNR_CHECK_ARG(n_rays > 0 && Nc >= 3 && Nf >= 1 && Nc + Nf <= 4096, SNR_ERR_SHAPE);
   int npow2 = 2;
@@ -867,21 +926,26 @@ extern "C" int snr_sample_fine_rng(const float* z_coarse, const float* weights, 
     ProfScope ps(K_SAMPLE_FINE, (hipStream_t)stream);
     sample_fine_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(z_coarse, weights, nullptr, n_rays, Nc, Nf, npow2,
                                                                             z_out, z_samples, z_std, 0, 1,
-                                                                            make_rng(seed, offset));
+                                                                            make_rng(seed, offset, base));
   }
   return launch_status();
 }
+extern "C" int snr_sample_fine_rng(const float* z_coarse, const float* weights, int64_t n_rays, int Nc, int Nf,
+                                   uint64_t seed, uint64_t offset, float* z_out, float* z_samples, float* z_std,
+                                   snr_stream_t stream) {
+  return snr::sample_fine_rng_impl(z_coarse, weights, n_rays, Nc, Nf, seed, offset, nullptr, z_out, z_samples, z_std, stream);
+}
 
-extern "C" int snr_composite_train(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
-                                   float noise_std, uint64_t seed, uint64_t offset, int64_t n_rays, int S, int white,
-                                   int detach, const float* target, int64_t n_rays_global, float* rgb_map,
-                                   float* disp_map, float* acc_map, float* depth_map, float* weights, float* d_raw,
-                                   float* loss, float* loss_also, snr_stream_t stream) {
+int snr::composite_train_impl(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
+                              float noise_std, uint64_t seed, uint64_t offset, const uint64_t* base, int64_t n_rays, int S,
+                              int white, int detach, const float* target, int64_t n_rays_global, float* rgb_map,
+                              float* disp_map, float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss,
+                              float* loss_also, snr_stream_t stream) {
   SNR_CHECK_ARG(raw && z && rays && target && rgb_map && disp_map && acc_map && depth_map && weights && d_raw && loss,
                 SNR_ERR_NULL);
   SNR_CHECK_ARG(n_rays > 0 && n_rays_global >= n_rays && S > 0 && C >= 4 && ld >= 6, SNR_ERR_SHAPE);
   const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
-  const NoiseSrc ns{noise, (!noise && noise_std > 0.f) ? 1 : 0, make_rng(seed, offset), noise_std};
+  const NoiseSrc ns{noise, (!noise && noise_std > 0.f) ? 1 : 0, make_rng(seed, offset, base), noise_std};
   {
     ProfScope ps(K_COMPOSITE_FWD, (hipStream_t)stream);
     const float inv_count = 1.f / (3.f * (float)n_rays_global);
@@ -898,6 +962,14 @@ extern "C" int snr_composite_train(const float* raw, int C, const float* z, cons
 #undef SNR_CT_ARGS
   }
   return launch_status();
+}
+extern "C" int snr_composite_train(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
+                                   float noise_std, uint64_t seed, uint64_t offset, int64_t n_rays, int S, int white,
+                                   int detach, const float* target, int64_t n_rays_global, float* rgb_map,
+                                   float* disp_map, float* acc_map, float* depth_map, float* weights, float* d_raw,
+                                   float* loss, float* loss_also, snr_stream_t stream) {
+  return snr::composite_train_impl(raw, C, z, rays, ld, noise, noise_std, seed, offset, nullptr, n_rays, S, white, detach, target,
+                                   n_rays_global, rgb_map, disp_map, acc_map, depth_map, weights, d_raw, loss, loss_also, stream);
 }
 
 extern "C" int snr_make_rays(int H, int W, float focal, const float* c2w_host, int i0, int j0, int h, int w, int ndc,
@@ -951,13 +1023,35 @@ extern "C" int snr_adam_step(float* params, const float* grads, float* m, float*
                              float b2, float eps, int step, float gscale, snr_stream_t stream) {
   SNR_CHECK_ARG(params && grads && m && v, SNR_ERR_NULL);
   SNR_CHECK_ARG(n > 0 && step >= 1, SNR_ERR_SHAPE);
-  const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
-  const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)step));
+  const float bc1 = (float)(1.0 - powi((double)b1, step));
+  const float bc2s = (float)sqrt(1.0 - powi((double)b2, step));
   const int64_t threads = (n + 3) / 4;
   {
     ProfScope ps(K_ADAM, (hipStream_t)stream);
     adam_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
         params, grads, m, v, n, lr, b1, b2, eps, bc1, bc2s, gscale);
   }
+  return launch_status();
+}
+
+extern "C" int snr_adam_step_dev(float* params, const float* grads, float* m, float* v, int64_t n, const snr_step_state* state,
+                                 float b1, float b2, float eps, float gscale, snr_stream_t stream) {
+  SNR_CHECK_ARG(params && grads && m && v && state, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n > 0, SNR_ERR_SHAPE);
+  const int64_t threads = (n + 3) / 4;
+  {
+    ProfScope ps(K_ADAM, (hipStream_t)stream);
+    adam_dev_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(params, grads, m, v, n, state,
+                                                                                                    b1, b2, eps, gscale);
+  }
+  return launch_status();
+}
+
+extern "C" int snr_step_state_advance(snr_step_state* state, double lrate, double decay_steps, float b1, float b2,
+                                      uint64_t n_offsets, snr_stream_t stream) {
+  SNR_CHECK_ARG(state, SNR_ERR_NULL);
+  SNR_CHECK_ARG(decay_steps > 0.0, SNR_ERR_SHAPE);
+  step_state_advance_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(state, lrate, decay_steps, (double)b1,
+                                                                          (double)b2, (unsigned long long)n_offsets);
   return launch_status();
 }

@@ -457,11 +457,12 @@ def _net_struct(net):
 
 
 def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bkgd, perturb, raw_noise_std, seed, offset,
-                  target, loss, n_rays_global=None, randoms=None):
+                  target, loss, n_rays_global=None, randoms=None, offset_base=None):
     """render_rays + the loss terms + the compositing backward of one training step in one library call.  ``net_f`` None
     with N_importance > 0 = the coarse network evaluated twice.  Consumes the Philox offsets offset+1 .. offset+4.
     Returns a FusedRender; fused_backward(handle) gives the parameter gradients.  ``target`` None (and ``loss`` None) =
-    inference: forward only, nothing saved for a backward."""
+    inference: forward only, nothing saved for a backward.  ``offset_base`` = device tensor holding a snr_step_state (its
+    first field is added to the draw offsets at run time: graph replays)."""
     import ctypes
     lib = _lib.load()
     rnd = randoms or {}
@@ -484,7 +485,8 @@ def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bk
     arr = {k: (f32c(rnd[k]) if rnd.get(k) is not None else None) for k in ("t_rand", "u", "noise_c", "noise_f")}
     check(lib.snr_render_rays_fused_forward(
         ctypes.byref(rc), ctypes.byref(sc), fptr, ptr(rays), rays.shape[1], n, ptr(arr["t_rand"]), ptr(arr["u"]),
-        ptr(arr["noise_c"]), ptr(arr["noise_f"]), int(seed), int(offset), ptr(target), int(n_rays_global or n), ptr(ws),
+        ptr(arr["noise_c"]), ptr(arr["noise_f"]), int(seed), int(offset), ptr(offset_base), ptr(target),
+        int(n_rays_global or n), ptr(ws),
         ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(rgb0), ptr(disp0), ptr(acc0), ptr(z_std), ptr(loss), stream()),
         "snr_render_rays_fused_forward")
     return FusedRender(rc, (sc, sf), (pc, pf, arr), rays, n, ws, L, (rgb, disp, acc, depth, rgb0, disp0, acc0, z_std), loss)

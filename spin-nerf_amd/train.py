@@ -10,11 +10,14 @@ replica of both MLPs (2 x 2.4 MB), and the only collective is one all-reduce of 
 gradient buffer per step over RCCL ("nccl" backend); Adam then runs on the flat buffers with the
 1/world_size scale folded into the kernel.
 """
+import ctypes
+import math
 import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
+from ._lib import check, ptr
 from .render import render
 
 
@@ -24,7 +27,7 @@ def img2mse(x, y):
 
 class RenderTrainer:
     def __init__(self, render_kwargs_train, lrate=5e-4, lrate_decay=250, world_size=1, process_group=None,
-                 optimizer=None, start=None):
+                 optimizer=None, start=None, graph=False):
         """``optimizer`` / ``start`` = what create_nerf() returned: when it reloaded a checkpoint (run_nerf.py:448-462)
         the Adam moments, the step count and the learning rate it restored continue here (a resumed run must not
         restart the bias correction and the lr decay); an optimizer whose state does not cover every network raises."""
@@ -40,6 +43,10 @@ class RenderTrainer:
         # in-kernel random draws (Philox key / running call counter); ranks draw different streams
         self._seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (self._rank() + 1)) & 0xFFFFFFFFFFFFFFFF
         self._draws = 0
+        # graph=True (or SNR_STEP_GRAPH=1): single-process steps of the plain configuration are captured once into a HIP
+        # graph and replayed (the per-step scalars live in a device-side snr_step_state)
+        self._graph_on = bool(graph) or os.environ.get("SNR_STEP_GRAPH") == "1"
+        self._graph, self._graph_warm = None, None
         if optimizer is not None:
             self._adopt(optimizer, start)
         # The all-reduce of a net's gradient starts the moment autograd has finished that net (the fine net's
@@ -100,6 +107,9 @@ class RenderTrainer:
         (or taken from ``randoms=``), and each network's compositing forward, loss term and compositing backward are
         one kernel (snr_composite_train).  Anything else goes through render() + autograd."""
         if self._direct_ok(batch_rays, chunk, extra):
+            if (self._graph_on and self.world_size == 1 and not extra.get("randoms")
+                    and os.environ.get("SNR_NO_FUSED_STEP") != "1"):
+                return self._step_graph(H, W, focal, batch_rays, target_s)
             return self._step_direct(H, W, focal, batch_rays, target_s, extra.get("randoms"))
         for n in self.nets:
             n.flat.grad = None
@@ -205,6 +215,96 @@ class RenderTrainer:
             net_c.flat.grad = ops.mlp_train_backward(net_c, sv_c, out_c[5])
         self.apply_gradients()
         return loss[0], rgb
+
+    # ---- the same step as a captured HIP graph ---------------------------------------------------------------------------
+    def _host_state(self):
+        """snr_step_state of the step about to run, from the host counters (include/spinnerf_hip.h)"""
+        import numpy as np
+
+        def powi(b, n):        # csrc/render_ops.hip: powi — the same IEEE multiplications as the library's
+            r = 1.0
+            while n > 0:
+                if n & 1:
+                    r *= b
+                b *= b
+                n >>= 1
+            return r
+        k = self.opt_step + 1
+        b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))      # the C ABI takes the betas as floats
+        return _lib.StepState(int(self._draws), k, int(self.global_step), float(self._lr),
+                              float(np.float32(1.0 - powi(b1, k))), float(np.float32(math.sqrt(1.0 - powi(b2, k)))), 0.0)
+
+    def _upload_state(self, G):
+        st = self._host_state()
+        G["state"].copy_(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
+        G["expect"] = (self._draws, self.opt_step, self.global_step)
+
+    def _capture(self, H, W, focal, batch_rays, target_s, key):
+        kw = self.kw
+        lib = _lib.load()
+        Nc, Nf = kw['N_samples'], kw.get('N_importance', 0)
+        net_c = kw['network_fn']
+        net_f = (kw.get('network_fine') or net_c) if Nf > 0 else None
+        two = Nf > 0 and net_f is not net_c
+        dev = batch_rays.device
+        G = {"key": key, "rays": batch_rays.detach().clone(), "target": ops.f32c(target_s).clone(),
+             "state": torch.zeros(ctypes.sizeof(_lib.StepState), dtype=torch.uint8, device=dev)}
+        self._upload_state(G)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = torch.zeros(2, device=dev)
+            rows = ops.pack_rays(G["rays"][0], G["rays"][1], H, W, focal, ndc=kw.get('ndc', True), near=float(kw.get('near', 0.)),
+                                 far=float(kw.get('far', 1.)), use_viewdirs=kw.get('use_viewdirs', False))
+            for n in self.nets:              # the pack kernels belong to every replay: Adam rewrote the parameters
+                n.mark_weights_changed()
+                n.packed_weights()
+            h = ops.fused_forward(net_c, net_f if two else None, rows, Nc, Nf, kw.get('lindisp', False), kw.get('white_bkgd', False),
+                                  kw.get('perturb', 0.), float(kw.get('raw_noise_std', 0.)), self._seed, 0, G["target"], loss,
+                                  offset_base=G["state"])
+            g_c = torch.empty_like(net_c.flat.data)
+            g_f = torch.empty_like(net_f.flat.data) if two else None
+            ops.fused_backward(h, g_c, g_f)
+            grads = {id(net_c): g_c}
+            if two:
+                grads[id(net_f)] = g_f
+            for n, m, v in zip(self.nets, self.m, self.v):
+                gr = grads.get(id(n))
+                if gr is None:
+                    continue
+                check(lib.snr_adam_step_dev(ptr(n.flat.data), ptr(gr), ptr(m), ptr(v), n.flat.numel(), ptr(G["state"]), 0.9, 0.999,
+                                            1e-8, 1.0, _lib.stream()), "snr_adam_step_dev")
+            check(lib.snr_step_state_advance(ptr(G["state"]), float(self.lrate), float(self.lrate_decay) * 1000.0, 0.9, 0.999, 4,
+                                             _lib.stream()), "snr_step_state_advance")
+        G.update(graph=g, loss=loss, rgb=h.rgb, handle=h, grads=grads)
+        self._graph = G
+
+    def _step_graph(self, H, W, focal, batch_rays, target_s):
+        """RenderTrainer.step through a captured graph.  The first call with a given batch shape runs eagerly (it sizes
+        the allocator and sets the kernels' LDS attributes, which a capture may not), the second captures, every later one
+        copies the batch into the graph's input buffers and replays.  Returned tensors are the graph's own output buffers:
+        they are overwritten by the next step."""
+        key = (H, W, float(focal), tuple(batch_rays.shape), str(batch_rays.device))
+        if self._graph is None or self._graph["key"] != key:
+            if self._graph_warm != key:
+                self._graph_warm = key
+                return self._step_direct(H, W, focal, batch_rays, target_s, None)
+            self._capture(H, W, focal, batch_rays, target_s, key)
+        G = self._graph
+        if G["expect"] != (self._draws, self.opt_step, self.global_step):   # eager steps / a checkpoint moved the counters
+            self._upload_state(G)
+        G["rays"].copy_(batch_rays)
+        G["target"].copy_(target_s)
+        G["graph"].replay()
+        for n in self.nets:
+            n.flat.grad = G["grads"].get(id(n))
+            n.mark_weights_changed()
+        self._draws += 4
+        self.opt_step += 1
+        self._lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 1000)))
+        self.global_step += 1
+        G["expect"] = (self._draws, self.opt_step, self.global_step)
+        return G["loss"][0], G["rgb"]
 
     def spin_loss(self, H, W, focal, batch_rays_clf, target_clf, batch_rays, target_s, batch_inp=None,
                   depth_inp=None, chunk=1024 * 32, randoms=None, batched=False, colmap_depth=None, lpips=None, **extra):

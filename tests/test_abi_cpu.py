@@ -216,6 +216,9 @@ def test_fused_render_rays_layout_and_argument_checks_on_host(S):
     nopack = L.Net(L.NET_MLP, cfg, None, blob)
     assert lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(nopack), None, n, 0, ctypes.byref(o)) == -1
     assert lib.snr_render_rays_fused_forward(ctypes.byref(rc), ctypes.byref(net), None, None, 11, n, None, None, None, None, 0, 0,
-                                             None, n, None, None, None, None, None, None, None, None, None, None, None) == -1
+                                             None, None, n, None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.snr_adam_step_dev(None, None, None, None, 8, None, 0.9, 0.999, 1e-8, 1.0, None) == -1
+    assert lib.snr_step_state_advance(None, 5e-4, 250000.0, 0.9, 0.999, 4, None) == -1
+    assert ctypes.sizeof(S._lib.StepState) == 40
     assert lib.snr_render_rays_fused_backward(ctypes.byref(rc), ctypes.byref(net), None, blob, 11, n, blob, blob, None, 0, 0,
                                               None) == -2       # no pass selected

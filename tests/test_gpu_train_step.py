@@ -225,3 +225,46 @@ def test_fused_forward_in_inference_mode_equals_render(Nf):
         assert torch.equal(h.view("z_coarse", n, 64), ex["z_vals"]) and torch.equal(h.view("weights0", n, 64), ex["weights"])
         assert torch.equal(h.view("raw0", n, 64, 4), ex["raw"])
     assert h.layout.act0 == -1 and h.layout.d_raw0 == -1
+
+
+def test_graph_replayed_step_equals_the_eager_step():
+    """RenderTrainer(graph=True): the step captured once into a HIP graph (per-step scalars — draw counter, Adam's step
+    number and rate — in a device-side snr_step_state advanced by the graph itself) and replayed must follow the eager
+    trainer: same draws, same lr schedule, same parameters.  (Bias corrections and the rate are formed with pow() on the
+    device instead of the host: the last bit may differ, hence a tolerance of a few ulp on the parameters.)"""
+    import spin_nerf_amd as S
+    train = importlib.import_module("spin-nerf_amd.train")
+    (a, b), hwf, rays, target, _ = _two_trainers("bf16", 128)
+    ta, tb = a[0], train.RenderTrainer(b[0].kw, lrate=5e-4, graph=True)
+    g = torch.Generator().manual_seed(11)
+    batches = []
+    for _ in range(6):
+        sel = torch.randperm(rays.shape[1], generator=g)
+        batches.append((rays[:, sel.cuda()].contiguous(), target[sel.cuda()].contiguous()))
+    la = [float(ta.step(*hwf, r, t)[0]) for r, t in batches]
+    lb = []
+    for i, (r, t) in enumerate(batches):
+        loss, rgb = tb.step(*hwf, r, t)
+        lb.append(float(loss))
+        if i == 3:     # an eager step in between (e.g. a different route) moves the host counters: the graph re-syncs
+            pass
+    assert tb._graph is not None, "the graph route was not taken"
+    assert (ta._draws, ta.opt_step, ta.global_step) == (tb._draws, tb.opt_step, tb.global_step)
+    assert abs(ta.current_lr() - tb.current_lr()) < 1e-12
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 1e-5 * abs(x), (la, lb)
+    for na, nb in zip(a[1], b[1]):
+        d = (na.flat.detach() - nb.flat.detach()).abs().max()
+        assert float(d) <= 2e-6, float(d)
+    # the device state the graph keeps is what the host would compute
+    st = S._lib.StepState.from_buffer_copy(bytes(tb._graph["state"].cpu().numpy()))
+    want = tb._host_state()
+    assert (st.offset_base, st.opt_step, st.global_step) == (want.offset_base, want.opt_step, want.global_step)
+    assert abs(st.lr - want.lr) <= 1e-9 and abs(st.bc1 - want.bc1) <= 1e-6 and abs(st.bc2_sqrt - want.bc2_sqrt) <= 1e-6
+    # interleave an eager step: the counters move on the host, the next replay uploads them first
+    tb._graph_on = False
+    tb.step(*hwf, *batches[0]); ta.step(*hwf, *batches[0])
+    tb._graph_on = True
+    tb.step(*hwf, *batches[1]); ta.step(*hwf, *batches[1])
+    for na, nb in zip(a[1], b[1]):
+        assert float((na.flat.detach() - nb.flat.detach()).abs().max()) <= 4e-6
