@@ -355,3 +355,32 @@ def test_autograd_free_step_equals_the_autograd_step_for_hash_networks(S, monkey
         rel = float((a.flat.grad - b.flat.grad).norm() / b.flat.grad.norm())
         assert rel < 1e-5, rel
         assert float(b.flat.grad.abs().max()) > 0
+
+
+def test_graph_replayed_step_with_hash_networks(S):
+    """the captured-graph route of RenderTrainer.step on NeRF_TCNN networks: counters, learning-rate schedule and the loss
+    trajectory follow the eager trainer (the table gradient is summed by atomics, so parameters agree only statistically)."""
+    import contextlib, io
+    RenderTrainer = importlib.import_module("spin-nerf_amd.train").RenderTrainer
+    dev = torch.device("cuda")
+    rs = np.random.RandomState(5)
+    n = 256
+    ro = torch.from_numpy(rs.normal(scale=0.2, size=(n, 3)).astype(np.float32)) + torch.tensor([0., 0., 4.])
+    rd = torch.from_numpy((rs.normal(size=(n, 3)) * [0.3, 0.3, 0.1] + [0, 0, -1]).astype(np.float32))
+    rays = torch.stack([ro, rd], 0).to(dev)
+    target = torch.from_numpy(rs.uniform(size=(n, 3)).astype(np.float32)).to(dev)
+    out = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            kw, *_ = S.create_nerf_tcnn(_args(raw_noise_std=1.0), device=dev)
+        kw.update(near=2.0, far=6.0)
+        tr = RenderTrainer(kw, lrate=1e-2, lrate_decay=250, graph=graph)
+        losses = [float(tr.step(24, 32, 40.0, rays, target)[0]) for _ in range(8)]
+        out.append((tr, losses))
+    (te, le), (tg, lg) = out
+    assert tg._graph is not None
+    assert (te._draws, te.opt_step, te.global_step) == (tg._draws, tg.opt_step, tg.global_step) and te.current_lr() == tg.current_lr()
+    assert le[-1] < le[0] and lg[-1] < lg[0], (le, lg)    # both runs descend (random targets: slowly)
+    for a, b in zip(le, lg):
+        assert abs(a - b) < 2e-2 * abs(a), (le, lg)
