@@ -284,7 +284,10 @@ class RenderTrainer:
         the allocator and sets the kernels' LDS attributes, which a capture may not), the second captures, every later one
         copies the batch into the graph's input buffers and replays.  Returned tensors are the graph's own output buffers:
         they are overwritten by the next step."""
-        key = (H, W, float(focal), tuple(batch_rays.shape), str(batch_rays.device))
+        # (the graph holds raw pointers: a parameter or moment buffer that moved — .to(), a re-created network — means a
+        #  new capture, not a replay into freed memory)
+        key = (H, W, float(focal), tuple(batch_rays.shape), str(batch_rays.device),
+               tuple(n.flat.data_ptr() for n in self.nets), tuple(m.data_ptr() for m in self.m + self.v))
         if self._graph is None or self._graph["key"] != key:
             if self._graph_warm != key:
                 self._graph_warm = key
