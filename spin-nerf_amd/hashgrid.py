@@ -12,7 +12,6 @@ All parameters live in one flat fp32 buffer [table | sigma_net | color_net] so t
 checkpoints treat it like the other networks of this package.
 """
 import math
-import os
 from collections import OrderedDict
 
 import torch
