@@ -132,7 +132,9 @@ class RenderTrainer:
         kw = self.kw
         if os.environ.get("SNR_NO_DIRECT_STEP") == "1" or set(extra) - {"randoms"}:
             return False
-        nets = [kw.get('network_fn')] + ([kw.get('network_fine')] if kw.get('N_importance', 0) > 0 else [])
+        # (no network_fine with N_importance > 0 = network_fn evaluated twice, run_nerf.py:705: the direct step handles it)
+        nets = [kw.get('network_fn')] + ([kw['network_fine']] if kw.get('N_importance', 0) > 0 and kw.get('network_fine') is not None
+                                        else [])
         from .hashgrid import NeRF_TCNN
         if any(type(n) not in (NeRF, NeRF_TCNN) for n in nets) or kw.get('sigma_loss') is not None:
             return False

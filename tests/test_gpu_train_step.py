@@ -268,3 +268,37 @@ def test_graph_replayed_step_equals_the_eager_step():
     tb.step(*hwf, *batches[1]); ta.step(*hwf, *batches[1])
     for na, nb in zip(a[1], b[1]):
         assert float((na.flat.detach() - nb.flat.detach()).abs().max()) <= 4e-6
+
+
+def test_one_network_for_both_passes_fused_vs_per_kernel(monkeypatch):
+    """N_importance > 0 without a fine network: the reference evaluates network_fn twice (run_nerf.py:705) and autograd
+    sums both passes' gradients into it.  The fused library route (fine == NULL: the coarse pass accumulates onto the fine
+    pass's gradient) must equal the per-kernel route (g_coarse + g_fine), and both the render() + autograd route."""
+    import spin_nerf_amd as S
+    train = importlib.import_module("spin-nerf_amd.train")
+    (a, b), hwf, rays, target, _ = _two_trainers("bf16", 128)
+    trainers = []
+    for tr, nets in (a, b):
+        kw = dict(tr.kw); kw["network_fine"] = None
+        trainers.append((train.RenderTrainer(kw, lrate=5e-4), nets[0]))
+    (ta, na), (tb, nb) = trainers
+    assert len(ta.nets) == 1 and ta._direct_ok(rays, 32768, {})
+    la, rgb_a = ta.step(*hwf, rays, target)
+    monkeypatch.setenv("SNR_NO_FUSED_STEP", "1")
+    lb, rgb_b = tb.step(*hwf, rays, target)
+    assert torch.equal(rgb_a, rgb_b)
+    assert torch.equal(na.flat.grad, nb.flat.grad)
+    assert torch.equal(na.flat.detach(), nb.flat.detach())
+    # against autograd through render() (its own draws: compare on injected ones)
+    (c, d), hwf, rays, target, rnd = _two_trainers("bf16", 128)
+    rnd = {k: v for k, v in rnd.items() if v is not None}
+    outs = []
+    for (tr, nets), no_direct in ((c, "0"), (d, "1")):
+        kw = dict(tr.kw); kw["network_fine"] = None
+        t2 = train.RenderTrainer(kw, lrate=5e-4)
+        monkeypatch.setenv("SNR_NO_FUSED_STEP", "0")
+        monkeypatch.setenv("SNR_NO_DIRECT_STEP", no_direct)
+        t2.step(*hwf, rays, target, randoms=rnd)
+        outs.append(nets[0].flat.grad.clone())
+    rel = float((outs[0] - outs[1]).norm() / outs[1].norm())
+    assert rel < 1e-5, rel
