@@ -1,5 +1,10 @@
+"""Diagnostic: parameters / gradients of the captured-graph route of RenderTrainer.step against the eager route, step by step,
+and the device-side snr_step_state against the host counters (found the one-ulp difference of pow() between host and
+device that made the two routes drift apart before the bias corrections were formed by squaring on both sides)."""
 import sys, importlib, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import spin_nerf_amd as S
 import test_gpu_train_step as T
 train = importlib.import_module("spin-nerf_amd.train")
