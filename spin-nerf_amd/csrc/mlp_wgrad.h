@@ -312,13 +312,22 @@ __device__ __forceinline__ void wgrad_run(const WgradLocal& L, char* smem, int w
     // 32 ta0 + i32 and, in registers 4k..4k+3, its columns 32 y + 8 k + 4 g32 + 0..3 — four neighbours of the row-major
     // partial plane, i.e. one 16-byte store instead of four 4-byte ones (the 160 scalar stores per wave were a visible
     // tail of this kernel).
-    float* prow = L.part + (int64_t)(32 * ta0 + i32) * NB + 4 * g32;
+    // bf16 mode writes the partial sums as bf16 (each plane in the first half of its fp32-sized slot): half the bytes of
+    // the split-K round trip (62 -> 31 MB written here and read back by the reduce kernel, per launch); a partial sum is
+    // the fp32 accumulation over this split's samples, rounded once — the same 2^-9 the operands already carry, summed
+    // in fp32 over the splits by the reduce kernel.
+    const int64_t pel = (int64_t)(32 * ta0 + i32) * NB + 4 * g32;
 #pragma unroll
     for (int y = 0; y < NTB; ++y) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const f32x4 v = {acc[0][y][4 * k], acc[0][y][4 * k + 1], acc[0][y][4 * k + 2], acc[0][y][4 * k + 3]};
-        __builtin_nontemporal_store(v, (f32x4*)(prow + 32 * y + 8 * k));
+        if constexpr (P == kBF16) {
+          const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          *(bf16x4*)((__bf16*)L.part + pel + 32 * y + 8 * k) = h;   // (plain store: 8-byte pieces, L2 merges them into sectors)
+        } else {
+          __builtin_nontemporal_store(v, (f32x4*)(L.part + pel + 32 * y + 8 * k));
+        }
       }
     }
     // lanes l and l^32 hold the two sample halves of the same neuron row (row = lane & 31)
@@ -445,16 +454,23 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, i
   const int64_t st = (int64_t)NA * NB;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   if (row_ok && !is_bias) {
-    const float* p = a.part + J.part_off + (int64_t)(O.row0 + ra) * NB + O.col0 + cb;
+    // plane sp of this job starts at float offset part_off + sp * st; bf16 mode keeps bf16 elements in its first half
+    const int64_t el = (int64_t)(O.row0 + ra) * NB + O.col0 + cb;
+    auto plane = [&](int sp) -> f32x4 {
+      const float* base = a.part + J.part_off + (int64_t)sp * st;
+      if constexpr (P == kBF16) {
+        const bf16x4 h = __builtin_nontemporal_load((const bf16x4*)((const __bf16*)base + el));
+        return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      } else {
+        return __builtin_nontemporal_load((const f32x4*)(base + el));
+      }
+    };
     int sp = r;
     for (; sp + 12 < J.n_splits; sp += 16) {
-      const f32x4 v0 = __builtin_nontemporal_load((const f32x4*)(p + (sp + 0) * st));
-      const f32x4 v1 = __builtin_nontemporal_load((const f32x4*)(p + (sp + 4) * st));
-      const f32x4 v2 = __builtin_nontemporal_load((const f32x4*)(p + (sp + 8) * st));
-      const f32x4 v3 = __builtin_nontemporal_load((const f32x4*)(p + (sp + 12) * st));
+      const f32x4 v0 = plane(sp), v1 = plane(sp + 4), v2 = plane(sp + 8), v3 = plane(sp + 12);
       s0 += v0 + v2; s1 += v1 + v3;
     }
-    for (; sp < J.n_splits; sp += 4) s0 += __builtin_nontemporal_load((const f32x4*)(p + sp * st));
+    for (; sp < J.n_splits; sp += 4) s0 += plane(sp);
   } else if (row_ok && O.bias_off >= 0) {
     for (int sp = r; sp < J.n_splits; sp += 4) s0[0] += a.part[J.bias_part_off + (int64_t)sp * NA + O.row0 + ra];
   }

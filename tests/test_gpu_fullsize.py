@@ -103,20 +103,26 @@ def test_backward_is_deterministic_and_linear_in_d_raw(S):
     assert rel < 1e-2, rel
 
 
-def test_split_gradient_equals_whole(S):
-    """Backward of 196 608 samples in one launch vs accumulated over two halves (different split-K
-    partition of the samples): equal up to fp32 summation order."""
-    _, net = _net(S, 14)
-    pts, dirs = _inputs(5)
-    d = torch.randn(N_RAYS, N_C + N_F, 4, generator=torch.Generator().manual_seed(6)).cuda()
+@pytest.mark.parametrize("precision,gate", [("fp32", 1e-5), ("bf16", 6e-3)])
+def test_split_gradient_equals_whole(S, precision, gate):
+    """Backward of 196 608 samples in one launch vs accumulated over two halves (a different split-K partition of the
+    samples).  fp32 mode keeps its split-K partial sums in fp32: equal up to summation order (1e-5) — the strict check of
+    the split-K machinery, which both modes share.  bf16 mode rounds every partial sum once to bf16 (half the bytes of the
+    partial-sum round trip): with the random gradients of this test, whose per-sample contributions cancel almost
+    completely, that shows as 2.6e-3 of the gradient's norm — unbiased, and far inside the 1-3 % by which the bf16
+    network's gradient differs from the fp32 one."""
+    _, net = _net(S, 14, precision)
+    n_rays = N_RAYS if precision == "bf16" else N_RAYS // 4          # (the fp32 MFMA path is 16x slower)
+    pts, dirs = _inputs(5, n_rays)
+    d = torch.randn(n_rays, N_C + N_F, 4, generator=torch.Generator().manual_seed(6)).cuda()
     whole = _grad(net, pts, dirs, d)
     net.flat.grad = None
-    h = N_RAYS // 2
+    h = n_rays // 2
     net.query(pts[:h], dirs[:h]).backward(d[:h])
     net.query(pts[h:], dirs[h:]).backward(d[h:])
     halves = net.flat.grad.clone()
     rel = float((whole - halves).norm() / whole.norm())
-    assert rel < 1e-5, rel
+    assert rel < gate, rel
 
 
 def test_training_step_at_bench_size(S):
@@ -154,7 +160,8 @@ def test_training_step_at_bench_size(S):
 def test_one_launch_beyond_4_gib_of_saved_activations(S):
     """1 048 576 samples in one launch: 5.7 GB of saved activations and 5.2 GB of d z, i.e. section offsets
     past 2^32 in the asm stores, the dgrad flag loads and the wgrad DMA addresses.  Must equal the same
-    samples pushed through in four launches (forward bit-exact, gradients up to fp32 summation order)."""
+    samples pushed through in four launches (forward bit-exact; gradients up to the rounding of the bf16 split-K partial
+    sums — see test_split_gradient_equals_whole — where an addressing error would show as O(1))."""
     _, net = _net(S, 15)
     n_rays, s = 4096, 256
     pts, dirs = _inputs(7, n_rays, s)
@@ -173,4 +180,4 @@ def test_one_launch_beyond_4_gib_of_saved_activations(S):
         parts.append(o.detach())
     assert torch.equal(whole.detach(), torch.cat(parts, 0))
     rel = float((g_whole - net.flat.grad).norm() / g_whole.norm())
-    assert torch.isfinite(g_whole).all() and rel < 1e-5, rel
+    assert torch.isfinite(g_whole).all() and rel < 6e-3, rel

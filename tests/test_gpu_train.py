@@ -89,9 +89,9 @@ def test_bf16_training_matches_fp32_psnr():
 
     The per-step training PSNR of this scene swings by +-1.2 dB (standard deviation of a 50-step mean across seeds), so the
     comparison is made on a long window.  Measured on MI355X (tests/probes/psnr_gap.py, profiles/r02_psnr_gap.txt): 4000
-    iterations, 12 seeds with independent batch sequences, paired by seed — mean of the last 500 steps bf16 32.97 dB, fp32
-    32.80 dB, paired difference +0.17 dB with standard error 0.12 (standard deviation of a single pair 0.42); the 500 steps
-    before: +0.02 +- 0.16: no gap at the measurement's resolution, consistent with BASELINE.json's +-0.1 dB.  This
+    iterations, 12 seeds with independent batch sequences, paired by seed — mean of the last 500 steps bf16 32.88 dB, fp32
+    32.80 dB, paired difference +0.09 dB with standard error 0.12 (standard deviation of a single pair 0.43); the 500 steps
+    before: +0.04 +- 0.09: no gap at the measurement's resolution, consistent with BASELINE.json's +-0.1 dB.  This
     test is the one-seed, 1200-iteration version of that: the last-400-step means within 0.8 dB (2 sd of a pair), and
     both paths above 24 dB."""
     iters = 1200
