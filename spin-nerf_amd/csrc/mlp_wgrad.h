@@ -459,7 +459,7 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, i
     auto plane = [&](int sp) -> f32x4 {
       const float* base = a.part + J.part_off + (int64_t)sp * st;
       if constexpr (P == kBF16) {
-        const bf16x4 h = __builtin_nontemporal_load((const bf16x4*)((const __bf16*)base + el));
+        const bf16x4 h = *(const bf16x4*)((const __bf16*)base + el);   // (plain load: the partials were just written; A/B −6 %)
         return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
       } else {
         return __builtin_nontemporal_load((const f32x4*)(base + el));
