@@ -24,6 +24,7 @@
 #include "mlp_pack.h"
 #include "mlp_device.h"
 #include "mlp_wgrad.h"
+#include "mlp_wgrad_pair.h"
 
 namespace snr {
 
@@ -38,6 +39,7 @@ struct DgradArgs {
   int out_ch;
   const char* act;        // forward workspace (masks)
   char* ws;               // d z sections
+  int save_even;          // 0: d z0, d z2, d z4, d z6 are not saved (rebuilt by the weight-gradient pass)
 };
 
 template <int P, bool VD>
@@ -185,13 +187,13 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
       roll_masks(W6{});
       mask_load(AL.k_mask(i - 3 >= 0 ? i - 3 : 0), mk_next);
       stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], true,
-            [&](int nt) { ws_store(WL.k_dz(i - 1), IH{}, &hA[0][0], IH{}, nt, I8{}); });
+            [&](int nt) { if (a.save_even) ws_store(WL.k_dz(i - 1), IH{}, &hA[0][0], IH{}, nt, I8{}); });
     }
     // i = 1: d z0 from d z1 (hB) -> hA
     roll_masks(W6{});
     stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], true,
           [&](int nt) { ws_store(WL.k_dz(1), IH{}, &hB[0][0], IH{}, nt, I8{}); });
-    ws_store(WL.k_dz(0), IH{}, &hA[0][0], IH{}, 0, I1{});
+    if (a.save_even) ws_store(WL.k_dz(0), IH{}, &hA[0][0], IH{}, 0, I1{});
   }
   pipe.drain();
 }
@@ -231,7 +233,9 @@ static int check_cfg_b(const snr_mlp_config* c) {
 
 template <int P> static int64_t ws_bytes(const snr_mlp_config* c, int64_t n) {
   int64_t pf; int ts;
-  make_jobs<P>(c, n, &pf, &ts);
+  const bool rc = P == kBF16 && recompute_enabled();
+  make_jobs<P>(c, n, &pf, &ts, rc);
+  if (rc) pf += make_pair_plan(c, n, pf).part_floats;
   return WsLayout<P>(n, c->use_viewdirs).dz_bytes() + (pf + kPostFloats) * 4;
 }
 
@@ -271,15 +275,37 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   d.bwd_blocks = T.bwd_frags / kBlockFrags;
   d.d_raw = d_raw; d.n_samples = n; d.out_ch = c->out_ch;
   d.act = (const char*)act; d.ws = (char*)ws;
+  const bool rc = P == kBF16 && recompute_enabled();
+  d.save_even = !rc;
   int st = c->use_viewdirs ? launch_dgrad<P, true>(d, s) : launch_dgrad<P, false>(d, s);
   if (st != SNR_OK) return st;
 
   int64_t pf; int total_splits;
-  WgradArgs w = make_jobs<P>(c, n, &pf, &total_splits);
+  WgradArgs w = make_jobs<P>(c, n, &pf, &total_splits, rc);
   w.act = (const char*)act;
   w.ws = (const char*)ws;
   w.part = (float*)((char*)ws + WsLayout<P>(n, c->use_viewdirs).dz_bytes());
+  PairPlan pp{};
+  if constexpr (P == kBF16) {
+    if (rc) {
+      // the trunk layers: layer-pair kernel with selective recompute (mlp_wgrad_pair.h), its partial planes behind the plain pass's
+      pp = make_pair_plan(c, n, pf);
+      pp.pa.act = w.act; pp.pa.ws = w.ws; pp.pa.part = w.part;
+      pp.pa.blob = (const char*)packed;
+      pp.pa.bias = (const float*)((const char*)packed + (int64_t)(T.fwd_frags + T.bwd_frags) * 1024);
+      pp.red.act = w.act; pp.red.ws = w.ws; pp.red.part = w.part;
+      pf += pp.part_floats;
+      if (int e = ensure_dynamic_lds<&mlp_wgrad_pair_kernel>(kLdsBytes)) return e;
+      {
+        ProfScope ps(K_MLP_WGRAD_PAIR, s);
+        mlp_wgrad_pair_kernel<<<dim3((unsigned)pp.grid), dim3(64 * kPairWaves), kLdsBytes, s>>>(pp.pa);
+      }
+      st = launch_status();
+      if (st != SNR_OK) return st;
+    }
+  }
   w.post = w.part + pf;
+  pp.red.post = w.post;
   constexpr int lds = WgradCfg<P>::RING * 2 * Blob<P>::KS_H * 1024;   // the largest ring of any job (mlp_wgrad.h)
   if (int e = ensure_dynamic_lds<&mlp_wgrad_kernel<P>>(lds)) return e;
   {
@@ -292,6 +318,7 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   {
     ProfScope ps(K_MLP_WGRAD_REDUCE, s);
     mlp_wgrad_reduce_kernel<P><<<dim3((per_out + 255) / 256, (unsigned)w.n_outs), dim3(256), 0, s>>>(w, grad, accumulate);
+    if (rc) mlp_wgrad_reduce_kernel<P><<<dim3((per_out + 255) / 256, (unsigned)pp.red.n_outs), dim3(256), 0, s>>>(pp.red, grad, accumulate);
     if (c->use_viewdirs) {
       PostArgs pa{};
       pa.params = params; pa.post = w.post; pa.grad = grad;

@@ -95,6 +95,7 @@ struct FwdArgs {
   int out_ch;
   float* raw;
   char* act;               // null = inference
+  int save_even;           // 0: h0, h2, h4, h6 are not saved (the weight-gradient pass rebuilds them, mlp_wgrad_pair.h)
 };
 
 template <int P, bool VD, bool TRAIN>
@@ -264,7 +265,8 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     auto pre_of = [&](int s_prev, const Frag* src) {
       return [&, s_prev, src](int nt) {
         if constexpr (TRAIN) {
-          act_store(AL.k_h(s_prev), IH{}, src, IH{}, nt, I8{});
+          if (a.save_even || (s_prev & 1))
+            act_store(AL.k_h(s_prev), IH{}, src, IH{}, nt, I8{});
           if (nt == 0) mask_store(AL.k_mask(s_prev), pmask);
         }
       };
@@ -440,6 +442,7 @@ extern "C" int snr_mlp_forward(const snr_mlp_config* c, const void* packed, cons
   a.n_samples = n_samples; a.S = samples_per_ray;
   a.multires = T.multires; a.multires_views = T.multires_views; a.out_ch = c->out_ch;
   a.raw = raw; a.act = (char*)act;
+  a.save_even = !(bf && recompute_enabled());
   hipStream_t s = (hipStream_t)stream;
   const bool vd = c->use_viewdirs, tr = act != nullptr;
 #define SNR_FWD(P_) \

@@ -61,6 +61,7 @@ struct WgradOut {
   int cols_valid;               // valid true columns of the B side
   int bias_off;                 // destination bias or -1
   int to_scratch;               // 1: destination offsets are relative to the G block (stored, never accumulated)
+  int transposed;               // 1: the A side indexes weight COLUMNS and the B side weight ROWS (mlp_wgrad_pair.h, kind A)
 };
 constexpr int kMaxJobs = 12, kMaxOuts = 20;
 struct WgradArgs {
@@ -485,12 +486,13 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, i
     if (O.bias_off >= 0) dst[O.bias_off + n] = acc ? dst[O.bias_off + n] + s[0] : s[0];
     return;
   }
-  float* grow = dst + O.w_off + (int64_t)n * O.ld + O.col_off;
+  float* grow = O.transposed ? dst + O.w_off + O.col_off + n : dst + O.w_off + (int64_t)n * O.ld + O.col_off;
+  const int64_t kstride = O.transposed ? O.ld : 1;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int k = slot_true_index<P>(O.b_kind, cb + e, O.L);
     if (k < 0 || k >= O.cols_valid) continue;
-    grow[k] = acc ? grow[k] + s[e] : s[e];
+    grow[k * kstride] = acc ? grow[k * kstride] + s[e] : s[e];
   }
 }
 
@@ -590,8 +592,11 @@ int wgrad_launch_bf16(const WgradArgs& w, int total_splits, float* grad, int acc
 // ------------------------------------------------------------------------------------------
 // host: job list
 // ------------------------------------------------------------------------------------------
+// recompute = the trunk layers are handled by the layer-pair kernel (mlp_wgrad_pair.h): what stays here is the skip layer's
+// encoding columns and the layers above the trunk
 template <int P>
-static WgradArgs make_jobs(const snr_mlp_config* c, int64_t n_samples, int64_t* part_floats, int* total_splits) {
+static WgradArgs make_jobs(const snr_mlp_config* c, int64_t n_samples, int64_t* part_floats, int* total_splits,
+                           bool recompute = false) {
   using B = Blob<P>;
   constexpr int SPF = 2 * Prec<P>::EPF;   // k-slots per frag
   const int vd = c->use_viewdirs;
@@ -625,11 +630,15 @@ static WgradArgs make_jobs(const snr_mlp_config* c, int64_t n_samples, int64_t* 
   // merged skip-layer job: its 36 KiB bf16 tile still leaves a 4-slot ring; fp32 (72 KiB tiles, 9 DMA instructions per
   // wave) keeps the two jobs apart
   const bool merge5 = P == kBF16;
-  {
+  if (recompute) {
+    // d z5 x pe: the encoding columns of the skip layer (its bias gradient comes with the pair kernel's row sums of d z5)
+    const int j = job(dz(kSkip + 1), none, pe, none);
+    out(j, 0, SH, SRC_H, 0, SPE, SRC_ENC_PTS, L_pts, L.w_pts[kSkip + 1], kW + ip, 0, 0, kW, ip, -1);
+  } else {
     const int j = job(dz(0), none, pe, none);
     out(j, 0, SH, SRC_H, 0, SPE, SRC_ENC_PTS, L_pts, L.w_pts[0], ip, 0, 0, kW, ip, L.b_pts[0]);
   }
-  for (int i = 1; i < 8; ++i) {
+  for (int i = 1; i < 8 && !recompute; ++i) {
     if (i == kSkip + 1) {
       if (merge5) {
         const int j = job(dz(i), none, pe, h(i - 1));

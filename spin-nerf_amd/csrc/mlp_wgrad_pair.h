@@ -1,0 +1,668 @@
+// Weight gradients of the eight trunk layers with selective recompute (bf16 mode, gfx950).  Included by mlp_bwd.hip.
+//
+// The plain split-K pass (mlp_wgrad.h) reads d z_i and h_{i-1} for every layer: 1 KB per sample per layer, after the
+// chain kernels wrote the same 1 KB.  Here the forward saves only the ODD hidden layers (h1, h3, h5, h7) and dgrad only
+// the odd d z (d z1, d z3, d z5, d z7); the trunk is handled as four layer PAIRS (2k, 2k+1), k = 0..3, each by two kinds
+// of workgroup that stream the SAME two saved tensors X = h_{2k-1} (k = 0: the positional encoding) and D = d z_{2k+1}:
+//
+//   kind A   rebuilds  h_{2k}   = relu(W_{2k} X + b_{2k})                 and accumulates  dW_{2k+1} = sum_s D (x) h_{2k}
+//   kind B   rebuilds  d z_{2k} = relu'(h_{2k}) * (W_{2k+1}^T D)          and accumulates  dW_{2k}   = sum_s d z_{2k} (x) X
+//            (relu' from the 1-bit flags the forward saves for every layer)
+//
+// A layer's 256 x 256 fp32 accumulator is half of a CU's register file, so the two kinds cannot share a workgroup; they
+// share the HBM fetch instead: the workgroups b and b ^ 8 run on the same XCD (block b -> XCD b % 8) and sweep the same
+// tiles at the same pace, so the second request of a tile is an L2 hit (tests/probes/l2_share.hip: two such workgroups
+// are served 12 TB/s of requests out of 6 TB/s of HBM).  Per sample and layer pair: 1 KB written by the chain kernels
+// and ~1 KB fetched here, against 4 KB + 4 KB without the recompute.  The price is twice the MFMAs of the plain pass —
+// this kernel is bound by the matrix pipe, not by the stream — so its shape is chosen for MFMA issue:
+//
+//   * 4 waves x 512 registers, one wave per SIMD; wave w owns the output columns [64 w, 64 w + 64) as two 32-column
+//     blocks: 256 accumulator registers, and the rebuild layer's weights for those columns (2 x 16 fragments = 128
+//     registers, read once from the packed blob: they are exactly the forward / dgrad weight fragments of that
+//     column block, mlp_pack.h) — the weight operand never touches LDS.
+//   * The rebuild is evaluated TRANSPOSED, R[sample][column] = X[sample][:] W[column][:]: the saved tile is the A
+//     operand as it lies in LDS (ds_read_b128, the chain kernels' fragment layout), the C tile comes out with lane =
+//     column, registers = 16 samples, and — after bias / relu / flags and conversion — IS the B operand of the
+//     accumulation over samples (the k-slot order of samples is free as long as the A side agrees: the transposing
+//     reads of D / X fetch the sample quadruples the C layout implies).  No LDS round trip, no cross-lane movement.
+//   * Every LDS read serves two MFMAs (the wave's two column blocks share the A operand).
+//   * Software pipeline over tiles: body i accumulates tile i with the operand rebuilt during body i-1 while it
+//     rebuilds tile i+1; all reads are inline asm with counted waits (mlp_device.h), DMA pieces of tile i+RING-1
+//     are dripped between the MFMAs; one barrier per tile.
+#pragma once
+#include "mlp_wgrad.h"
+
+namespace snr {
+
+struct PairHalf {
+  int64_t part_off;        // float offset of this kind's partial planes [n_splits][256 columns][32 NM rows] (bf16 in the
+                           // first half of each fp32-sized plane, like the plain pass)
+  int64_t bias_part_off;   // float offset of its bias partials [n_splits][256]
+  int w_frag;              // first fragment of the rebuild layer's weight image inside the packed blob
+  int bias_off;            // kind A: float offset of b_{2k} inside the blob's bias block
+};
+struct PairJob {
+  int64_t x_off;           // saved X section in the forward workspace ([n_tiles][x_ks KiB])
+  int64_t dz_off;          // saved d z_{2k+1} section in the backward workspace ([n_tiles][16 KiB])
+  int64_t flag_off;        // ReLU flags of layer 2k in the forward workspace ([n_tiles][1 KiB])
+  int x_ks;                // 16 (hidden layer) or 4 (positional encoding)
+  int slot_begin, n_splits;   // pair slots [slot_begin, slot_begin + n_splits): slot p = workgroups (16 (p / 8) + p % 8) + {0, 8}
+  PairHalf a, b;
+};
+constexpr int kMaxPairs = 4;
+struct PairArgs {
+  int n_pairs;
+  PairJob job[kMaxPairs];
+  const char* act;
+  const char* ws;
+  const char* blob;      // packed weights (forward section first)
+  const float* bias;     // bias block inside the blob
+  float* part;
+  int64_t n_tiles;
+};
+
+constexpr int kPairWaves = 4;
+#ifndef SNR_PAIR_ABLATE
+#define SNR_PAIR_ABLATE 0   // timing experiments (results are garbage): 1 no DMA in the tile loop, 2 no LDS waits, 4 no barrier,
+#endif                      // 8 no finishing VALU work (relu / flags), 16 no rebuild MFMAs, 32 no accumulating MFMAs, 64 no operand reads, 128 no row sums
+
+// ---- the static schedule of one tile-loop body --------------------------------------------------------------------
+// A body works on two tiles at once: it ACCUMULATES tile i (operand P(i), rebuilt by the previous body) and REBUILDS
+// tile i+1.  Its MFMAs come in operand STEPS of two (the wave's two column blocks share the A operand):
+//   R-step q     one fragment of tile i+1's rebuild section (ds_read_b128)             R[c] += frag x W[c][q]
+//   A-step (m,t) row tile m, k-step t of tile i's accumulation section (2 transposing reads)   acc[c][m] += frag x P[c][t]
+// Order: the first A-steps of k-step 0 lead (their reads were issued by the previous body, nothing in them depends on the
+// barrier), the barrier that publishes tile i+1 follows step 0, then R-steps and the remaining A-steps alternate, and the
+// last A-steps of k-step 1 trail the last R-step.  Under the leading steps the upper half of the previous rebuild (C
+// registers 8..15 = k-step 1's operand) is converted, under the trailing steps the lower half of the new one (k-step 0's
+// operand of the next body) — the k-step whose registers have just been used up; only the 16 cvt + finishing
+// instructions per half ever sit between two MFMAs.  Every LDS read is issued LA steps ahead of its MFMAs (R-steps: not
+// before the barrier), across the loop's back edge for the leading steps.  Completion is counted: LDS operations retire in
+// order, so the wait in front of a step allows exactly the reads issued since its own (PairProg::young).
+enum { EV_ISSUE = 0, EV_FLAGS, EV_STEP_A, EV_STEP_B, EV_CVT, EV_SYNC, EV_DMA, EV_SUM };
+template <int TYPE, int KX> struct PairCfg {
+  static constexpr bool PB = TYPE == 1;
+  static constexpr int KR = PB ? 16 : KX;        // fragments of the rebuild's contraction
+  static constexpr int NM = PB ? KX / 2 : 8;     // 32-row tiles of the accumulated product
+  static constexpr int XO = 0, DZO = KX * 1024, FO = (KX + 16) * 1024;   // tile sections inside a ring slot
+  static constexpr int SLOT = (KX + 16 + (PB ? 1 : 0)) * 1024;
+  static constexpr int FIT = kLdsBytes / SLOT;
+  static constexpr int RING = FIT < 5 ? FIT : 5;
+  static constexpr int NIX = KX / kPairWaves, NID = 16 / kPairWaves;     // 1 KiB DMA pieces per wave: X, D
+  static constexpr int NI = NIX + NID + (PB ? 1 : 0);                    // ... + this wave's quarter of the flags
+  static constexpr int RO = PB ? DZO : XO;       // section the rebuild reads (fragments as stored)
+  static constexpr int AO = PB ? XO : DZO;       // section the accumulation reads (transposing reads)
+  static constexpr int NR = KR, NA = 2 * NM, NS = NR + NA;               // operand steps of one body
+  static constexpr int LA = 4;                   // operand steps the LDS reads run ahead of their MFMAs
+  static constexpr int WIN = NS % 8 == 0 ? 8 : 5;   // operand register sets, step s uses set s % WIN (a divisor of NS, > LA;
+                                                 // only the LA + 1 sets with reads in flight are live)
+  static constexpr int LEADA = NM < 4 ? NM : 4;  // k-step 0 A-steps in front (step 0 ahead of the barrier)
+  static constexpr int TAILA = NM < 4 ? NM : 4;  // k-step 1 A-steps behind the last R-step
+  static constexpr int SYNC_STEP = 0;            // the barrier follows this step
+};
+
+template <int TYPE, int KX> struct PairProg {
+  using C = PairCfg<TYPE, KX>;
+  static constexpr int NS = C::NS, NM = C::NM, NR = C::NR, LA = C::LA, MAXEV = 4 * C::NS + 32;
+  int order[NS];   // >= 0: R-step q;  < 0: A-step ~e, e = t * NM + m
+  int ip[NS];      // position (= "in front of step ip") at which the step's reads are issued; < 0: NS + ip of the previous body
+  int kind[MAXEV], arg[MAXEV], nxt[MAXEV], n;
+  constexpr void push(int k, int a, int b) { kind[n] = k; arg[n] = a; nxt[n] = b; ++n; }
+  constexpr PairProg() : order{}, ip{}, kind{}, arg{}, nxt{}, n(0) {
+    // ---- step order ----
+    int s = 0, a0 = 0, a1 = 0, r = 0;
+    for (; a0 < C::LEADA; ++a0) order[s++] = ~(0 * NM + a0);
+    const int nA_mid = (NM - C::LEADA) + (NM - C::TAILA);
+    int am = 0;
+    while (r < NR || am < nA_mid) {
+      const bool pick_r = r < NR && (am >= nA_mid || (int64_t)r * nA_mid <= (int64_t)am * NR);
+      if (pick_r) order[s++] = r++;
+      else {
+        if (a0 < NM) order[s++] = ~(0 * NM + a0++);
+        else order[s++] = ~(1 * NM + a1++);
+        ++am;
+      }
+    }
+    for (; a1 < NM; ++a1) order[s++] = ~(1 * NM + a1);
+    // ---- issue positions ----
+    for (int i = 0; i < NS; ++i) {
+      ip[i] = i - LA;
+      if (order[i] >= 0 && ip[i] < C::SYNC_STEP + 1) ip[i] = C::SYNC_STEP + 1;   // rebuild reads: behind the barrier
+    }
+    // ---- events ----
+    // A step is [wait (even steps: for this step and the next)] MFMA a | reads for later steps, a slice of conversion work |
+    // MFMA b | DMA piece: the wave issues in order, so what sits between the two MFMAs runs in the shadow of the first and
+    // what follows the second in the shadow of the second.  The two conversions (upper half of the previous rebuild under
+    // the leading A-steps, lower half of the new one under the trailing A-steps) are cut into four slices of one packed
+    // word per column block each.
+    const int first_tail = NS - C::TAILA, n_head = first_rstep();
+    for (int p = 0; p < NS; ++p) {
+      push(EV_STEP_A, p, 0);
+      for (int i = 0; i < NS; ++i) if (ip[i] == p) push(EV_ISSUE, i, 0);
+      for (int i = 0; i < NS; ++i) if (ip[i] < 0 && ip[i] + NS == p) push(EV_ISSUE, i, 1);
+      if (C::PB && p == first_tail - 2) push(EV_FLAGS, 0, 1);   // flags of the next tile's k-step 0: used by the tail's slices
+      for (int d = 0; d < 4; ++d) {
+        if (p < n_head && d * n_head / 4 == p) push(EV_CVT, 4 * 1 + d, 0);                              // upper half, slice d
+        if (p >= first_tail && d * C::TAILA / 4 == p - first_tail) push(EV_CVT, 4 * 0 + d, 0);          // lower half, slice d
+      }
+      if (C::PB && p == NS - 1) push(EV_FLAGS, 1, 1);           // ... k-step 1: by the next body's leading slices
+      if (C::PB && p == n_head - 1) push(EV_SUM, 1, 0);
+      push(EV_STEP_B, p, 0);
+      if (p == C::SYNC_STEP) push(EV_SYNC, 0, 0);
+      if (p > C::SYNC_STEP && p - C::SYNC_STEP - 1 < C::NI) push(EV_DMA, p - C::SYNC_STEP - 1, 0);
+      if (C::PB && p == 0) push(EV_SUM, 0, 0);
+    }
+  }
+  constexpr int reads_of(int e) const {
+    return kind[e] == EV_ISSUE ? (order[arg[e]] >= 0 ? 1 : 2) : (kind[e] == EV_FLAGS ? 4 : 0);
+  }
+  // LDS reads issued behind event `issue` and in front of event `use` (cyclically, when the issue belongs to the previous body)
+  constexpr int between(int issue, int use) const {
+    int c = 0;
+    if (issue < use) { for (int j = issue + 1; j < use; ++j) c += reads_of(j); }
+    else { for (int j = issue + 1; j < n; ++j) c += reads_of(j); for (int j = 0; j < use; ++j) c += reads_of(j); }
+    return c;
+  }
+  constexpr int find(int k, int a) const { for (int j = 0; j < n; ++j) if (kind[j] == k && arg[j] == a) return j; return -1; }
+  // e: the EV_STEP_A event of an even step; its wait also covers step + 1 (one s_waitcnt per two steps), whose reads are the younger
+  constexpr int young_pair(int e) const { return between(find(EV_ISSUE, arg[e] + 1), e); }
+  constexpr int young_flags(int t, int e) const { return between(find(EV_FLAGS, t), e); }  // e: the event that uses them
+  constexpr int first_rstep() const { for (int i = 0; i < NS; ++i) if (order[i] >= 0) return i; return -1; }
+  constexpr bool valid() const {
+    if (NS % C::WIN || C::WIN <= LA || NS % 2) return false;
+    for (int i = 0; i < NS; ++i) {
+      if (ip[i] >= i - (i & 1) || (ip[i] < 0 && order[i] >= 0)) return false;      // issued before the pair's wait; R-steps never early
+      if (order[i] >= 0 && i >= NS - C::TAILA) return false;
+    }
+    // k-step 0 is used up before the tail rewrites its operand; k-step 1 only after the head rewrote it
+    for (int i = 0; i < NS; ++i) if (order[i] < 0) {
+      const int t = (~order[i]) / NM;
+      if (t == 0 && i >= NS - C::TAILA) return false;
+      if (t == 1 && i <= C::SYNC_STEP) return false;
+    }
+    return n <= MAXEV && C::SYNC_STEP + 1 + C::NI <= NS;
+  }
+};
+
+template <int OFF> __device__ __forceinline__ void pair_read16(bf16x8& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void pair_read16u(u32x4& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+#if SNR_PAIR_ABLATE & 2
+#define SNR_PAIR_LGKM(N) 15
+#else
+#define SNR_PAIR_LGKM(N) ((N) < 15 ? (N) : 15)
+#endif
+template <int N> __device__ __forceinline__ void pair_wait(bf16x8& f) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(SNR_PAIR_LGKM(N)));
+}
+template <int N> __device__ __forceinline__ void pair_wait(bf16x4& a, bf16x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(SNR_PAIR_LGKM(N)));
+}
+template <int N> __device__ __forceinline__ void pair_wait(bf16x8& a, bf16x8& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(SNR_PAIR_LGKM(N)));
+}
+template <int N> __device__ __forceinline__ void pair_wait(bf16x8& a, bf16x4& b, bf16x4& c) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(SNR_PAIR_LGKM(N)));
+}
+template <int N> __device__ __forceinline__ void pair_wait(bf16x4& a, bf16x4& b, bf16x4& c, bf16x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(SNR_PAIR_LGKM(N)));
+}
+template <int N> __device__ __forceinline__ void pair_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(SNR_PAIR_LGKM(N)));
+}
+
+// The 256 accumulator registers are the whole accumulator file of a one-wave-per-SIMD kernel; with the rebuild's own
+// 32 result registers the kernel holds more MFMA results than there are AGPRs, and left to itself the register
+// allocator rotates accumulator tiles through arch VGPRs (v_accvgpr_read / mov / write around every MFMA).  Every MFMA
+// is therefore inline asm: the accumulating ones with their tile tied in place in the accumulator file, the rebuild's
+// with theirs in arch VGPRs (once a kernel has accumulator-file operands the compiler selects the accumulator form for
+// every builtin MFMA, and there is no room left there).  Hazards the compiler no longer pads (cdna_hip_programming.md
+// §5.7): a VALU-written operand needs 2 wait states in front of the MFMA (pair_operand_ready: s_nop 1 tied to the
+// registers; the A operands come from LDS reads and their wait); an MFMA result needs 12 before a VALU read
+// (pair_r_complete in front of the conversions; the accumulators are read after the tile loop, behind nops).
+__device__ __forceinline__ void pair_mfma_acc(f32x16& acc, const bf16x8& a, const u32x4& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// FIRST: the chain's first MFMA takes the constant 0 as C — no initial value to materialise (a splat kept for that cost 16
+// registers per column block; kind A adds the bias when the tile leaves the fp32 registers).  Its extra operands are the
+// freshly converted k-step-1 operands: tying them here makes the conversion (the last reader of the previous R) precede
+// the statement that re-defines R, so that no copy of R is needed.
+__device__ __forceinline__ void pair_mfma_reb_first(f32x16& r, const bf16x8& a, const bf16x8& b, u32x4& p0, u32x4& p1) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %3, %4, 0" : "=&v"(r), "+v"(p0), "+v"(p1) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pair_mfma_reb(f32x16& r, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(r) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pair_r_complete(f32x16& r0, f32x16& r1) { asm volatile("s_nop 7\n\ts_nop 4" : "+v"(r0), "+v"(r1)); }
+__device__ __forceinline__ void pair_operand_ready(u32x4& b0, u32x4& b1) { asm volatile("s_nop 1" : "+v"(b0), "+v"(b1)); }
+
+// Kind B's finishing touches on one packed word (two samples of one neuron column), as fixed instruction sequences that
+// work in place: left to the compiler the 16 words of a k-step are expanded into several dozen temporaries at once, and
+// the weight fragments are spilled to make room.
+//   keep the low / high bf16 of x where bit `bit` of w0 / w1 (the two samples' flag words) is set; w0, w1 are consumed
+__device__ __forceinline__ void pk_and_flags(unsigned& x, unsigned& w0, unsigned& w1, unsigned bit) {
+  asm("v_bfe_i32 %1, %1, %3, 1\n\tv_bfe_i32 %2, %2, %3, 1\n\tv_bfi_b32 %1, %4, %1, %2\n\tv_and_b32 %0, %0, %1"
+      : "+v"(x), "+v"(w0), "+v"(w1) : "v"(bit), "s"(0xffffu));
+}
+//   sum += low bf16 + high bf16 of x  (v_dot2c_f32_bf16 against (1, 1): one instruction per word)
+//   (four words per statement: the compiler pads every asm statement whose output the next instruction reads)
+__device__ __forceinline__ void pk_sum_bf16(float& sum, const u32x4& x) {
+  asm("v_dot2c_f32_bf16 %0, %5, %1\n\tv_dot2c_f32_bf16 %0, %5, %2\n\tv_dot2c_f32_bf16 %0, %5, %3\n\tv_dot2c_f32_bf16 %0, %5, %4"
+      : "+v"(sum) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "s"(0x3f803f80u));
+}
+
+// WV: the wave index as a compile-time constant (kind A: which row tiles' sums this wave keeps is decided without branches)
+template <int TYPE, int KX, int WV>
+__device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, int split, char* smem, int wave, int lane) {
+  using C = PairCfg<TYPE, KX>;
+  using Frag = bf16x8;
+  constexpr bool PB = C::PB;
+  constexpr int KR = C::KR, NM = C::NM, NI = C::NI, RING = C::RING, SLOT = C::SLOT, NS = C::NS, WIN = C::WIN;
+  static constexpr PairProg<TYPE, KX> PG{};
+  static_assert(PG.valid(), "inconsistent body schedule");
+  const PairHalf& H = PB ? J.b : J.a;
+
+  // tiles split, split + n_splits, ... (the same sequence in the kind-A and the kind-B workgroup of a slot)
+  const int64_t tstep = J.n_splits;
+  const int64_t t1 = (a.n_tiles - split + tstep - 1) / tstep;   // >= 1: the host never makes more splits than tiles
+
+  // ---- DMA: this wave's pieces wave + 4 k of X and of D, and its quarter of the flag KiB -------------------------------
+  const char* xp = a.act + J.x_off + ((int64_t)split * KX + wave) * 1024;
+  const char* dp = a.ws + J.dz_off + ((int64_t)split * 16 + wave) * 1024;
+  const char* fp = a.act + J.flag_off + (int64_t)split * 1024;
+  const int64_t xs = (int64_t)KX * 1024 * tstep, dst_ = (int64_t)16 * 1024 * tstep, fs_ = (int64_t)1024 * tstep;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  // flags: the forward stores one u32x4 per lane (sample s, half g) = [g][s][word]; the LDS image is [g][word][s], so that
+  // the four samples a C register quad covers are one 16-byte read.  dword d = 64 wave + lane of the image:
+  const int fd = 64 * wave + lane;
+  const uint32_t f_lane = (uint32_t)((((fd >> 7) * 32 + (fd & 31)) * 4 + ((fd >> 5) & 3)) * 4);
+  int64_t issued = 0;   // tiles issued so far
+  auto issue_piece = [&](int slot, auto K_) {
+    constexpr int k = decltype(K_)::value;
+    char* sbase = smem + slot * SLOT;
+#if SNR_PAIR_ABLATE & 1
+    if (issued > 2 * RING) return;
+#endif
+    // (no LDS read may sit in the cycle in front of an LDS-DMA — mlp_device.h, Pipe::issue_one: the schedule places every
+    //  DMA piece behind a step's MFMAs, and the prologue's behind nothing)
+    if constexpr (k < C::NIX) {
+      __builtin_amdgcn_global_load_lds(xp + 4096 * k + lane16, SNR_LDS(sbase + C::XO + (wave + 4 * k) * 1024), 16, 0, 0);
+    } else if constexpr (k < C::NIX + C::NID) {
+      __builtin_amdgcn_global_load_lds(dp + 4096 * (k - C::NIX) + lane16, SNR_LDS(sbase + C::DZO + (wave + 4 * (k - C::NIX)) * 1024), 16, 0, 0);
+    } else if constexpr (PB && k == C::NIX + C::NID) {
+      __builtin_amdgcn_global_load_lds(fp + f_lane, SNR_LDS(sbase + C::FO + wave * 256), 4, 0, 0);
+    }
+  };
+  auto advance = [&]() {   // past the end the last tile is loaded again: every body issues the same NI instructions
+    if (issued + 1 < t1) { ++issued; xp += xs; dp += dst_; fp += fs_; }
+  };
+
+  // ---- weights of this wave's two column blocks (registers for the whole kernel) ---------------------------------------
+  Frag W[2][KR];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int q = 0; q < KR; ++q)
+      W[c][q] = *(const Frag*)(a.blob + (((int64_t)H.w_frag + (2 * wave + c) * KR + q) * 64 + lane) * 16);
+  float bias_j[2] = {0.f, 0.f};   // (a literal zero for kind B: the additions below disappear)
+  if constexpr (!PB) {
+    bias_j[0] = a.bias[H.bias_off + 64 * wave + (lane & 31)];
+    bias_j[1] = a.bias[H.bias_off + 64 * wave + 32 + (lane & 31)];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int q = 0; q < KR; ++q) asm volatile("" : "+v"(W[c][q]));
+
+  // ---- per-lane LDS offsets ---------------------------------------------------------------------------------------------
+  // rebuild A operand: lane (sample s = lane & 31, k-half gg) reads its 16 bytes of fragment q (row act_row(s, q))
+  const int s32 = lane & 31, gg = lane >> 5;
+  const uint32_t lds0 = lds_addr(smem);
+  const uint32_t rdE = C::RO + gg * 16 + s32 * 32, rdO = C::RO + gg * 16 + (s32 ^ 4) * 32;
+  // accumulation A operand (transposing reads, mlp_wgrad.h): 16-lane group (gg, bh) receives neuron column ip of the
+  // [4 samples][16 neurons] block of fragment 2 m + bh whose samples are 16 t + 8 q + 4 gg + 0..3 — the k-slot order the
+  // rebuilt C tile implies: register 8 t + e of lane half gg holds sample 16 t + 8 (e >> 2) + 4 gg + (e & 3)
+  const int ip = lane & 15, bh = (lane >> 4) & 1, c4 = ip & 3, r4 = ip >> 2;
+  const uint32_t trA = C::AO + bh * 1024 + (((4 * gg + r4) ^ (4 * bh)) * 32) + c4 * 8;   // + m * 2048 + t * 512 + q * 256
+  // flags of column n = 32 cb + i of layer 2k (chain tile nt = cb, lane half g_n, C register r_n): word nt >> 1, bit below
+  uint32_t fl_addr[2] = {0, 0}, fl_bit[2] = {0, 0};
+  if constexpr (PB) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int nt = 2 * wave + c, i = lane & 31;
+      const int r_n = (i & 3) + 4 * (i >> 3), g_n = (i >> 2) & 1;
+      fl_bit[c] = (r_n >> 1) + 8 * (nt & 1) + 16 * (r_n & 1);
+      fl_addr[c] = C::FO + ((g_n * 4 + (nt >> 1)) * 32 + 4 * gg) * 4;   // + 32 j: samples 8 j + 4 gg + 0..3
+    }
+  }
+
+  f32x16 acc[2][NM];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][m][r] = 0.f;
+  float bsum[2] = {0.f, 0.f};   // kind A: row sums of D for row tiles 2 wave, 2 wave + 1; kind B: column sums of the rebuilt d z
+
+  // ---- state carried from body to body ----
+  f32x16 R[2];                   // rebuild of the next tile (fp32); its upper half is converted by the next body
+  u32x4 P[2][2];                 // [column block][k-step]: the current tile's operand, packed bf16
+  u32x4 fw[2][2];                // kind B: flag words of one k-step, [column block][quad]
+  Frag rf[WIN];                  // operand registers in flight
+  bf16x4 tl[WIN], th[WIN];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R[c][r] = 0.f;
+    P[c][0] = P[c][1] = fw[c][0] = fw[c][1] = u32x4{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int i = 0; i < WIN; ++i) { rf[i] = Frag{0, 0, 0, 0, 0, 0, 0, 0}; tl[i] = th[i] = bf16x4{0, 0, 0, 0}; }
+
+  int slot = RING - 1, slot_next = 0, islot = RING - 2;   // body -1: "tile -1" lives in the (empty) last slot
+
+  // slice d of half h of R -> packed word d of P[.][h] (+ bias, relu | flags): two C registers per column block
+  auto convert_slice = [&](auto H_, auto D_) {
+    constexpr int h = decltype(H_)::value, d = decltype(D_)::value;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    // (the two column blocks side by side: a packed fp32 add needs a wait state in front of its consumer)
+    f32x2_t v[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      v[c] = f32x2_t{R[c][8 * h + 2 * d], R[c][8 * h + 2 * d + 1]};
+      if constexpr (!PB) v[c] += f32x2_t{bias_j[c], bias_j[c]};
+    }
+    unsigned x[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) x[c] = __builtin_bit_cast(unsigned, __builtin_convertvector(v[c], bf16x2_t));
+#if !(SNR_PAIR_ABLATE & 8)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if constexpr (PB) {
+        // C registers 8 h + 2 d, + 1: quad (d >> 1) of this k-step's flag words, words 2 (d & 1), + 1 of it
+        unsigned w0 = fw[c][d >> 1][2 * (d & 1)], w1 = fw[c][d >> 1][2 * (d & 1) + 1];
+        pk_and_flags(x[c], w0, w1, fl_bit[c]);
+      } else {
+        x[c] = pk_relu_bf16(x[c]);
+      }
+    }
+#endif
+    P[0][h][d] = x[0];
+    P[1][h][d] = x[1];
+    if constexpr (d == 3) pair_operand_ready(P[0][h], P[1][h]);
+  };
+
+  // One body.  FIRST = body -1: rebuilds tile 0, accumulates nothing.
+  auto body = [&](auto FIRST_) {
+    constexpr bool FIRST = decltype(FIRST_)::value;
+    const uint32_t sA = lds0 + slot * SLOT, sN = lds0 + slot_next * SLOT;
+    const uint32_t aE = sN + rdE, aO = sN + rdO, aT = sA + trA, aTn = sN + trA;
+    static_for<0, PG.n>([&](auto I_) {
+      constexpr int ei = decltype(I_)::value;
+      constexpr int kind = PG.kind[ei], arg = PG.arg[ei], nxt = PG.nxt[ei];
+      if constexpr (kind == EV_ISSUE && !(SNR_PAIR_ABLATE & 64)) {
+        constexpr int o = PG.order[arg];
+        if constexpr (o >= 0) {
+          pair_read16<o * 1024>(rf[arg % WIN], (o & 1) ? aO : aE);
+        } else {
+          constexpr int e = ~o, t = e / NM, m = e % NM;
+          tr_read<m * 2048 + t * 512>(tl[arg % WIN], nxt ? aTn : aT);
+          tr_read<m * 2048 + t * 512 + 256>(th[arg % WIN], nxt ? aTn : aT);
+        }
+      } else if constexpr (kind == EV_FLAGS) {
+        // flags of the NEXT tile (its slot holds them since this body's barrier), quads 2 t, 2 t + 1 of both column blocks
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const uint32_t fa = sN + fl_addr[c];
+          pair_read16u<64 * arg>(fw[c][0], fa);
+          pair_read16u<64 * arg + 32>(fw[c][1], fa);
+        }
+      } else if constexpr (kind == EV_STEP_A || kind == EV_STEP_B) {
+        constexpr int o = PG.order[arg];
+        constexpr int c = kind == EV_STEP_B ? 1 : 0;   // the column block of this MFMA
+        if constexpr (kind == EV_STEP_A && arg % 2 == 0) {   // one wait per two steps
+          constexpr int young = PG.young_pair(ei);
+          constexpr int o1 = PG.order[arg + 1];
+          constexpr int w0 = arg % WIN, w1 = (arg + 1) % WIN;
+          if constexpr (o >= 0 && o1 >= 0) pair_wait<young>(rf[w0], rf[w1]);
+          else if constexpr (o >= 0) pair_wait<young>(rf[w0], tl[w1], th[w1]);
+          else if constexpr (o1 >= 0) pair_wait<young>(rf[w1], tl[w0], th[w0]);
+          else pair_wait<young>(tl[w0], th[w0], tl[w1], th[w1]);
+        }
+        if constexpr (o >= 0) {
+          Frag& x = rf[arg % WIN];
+          if constexpr (!(SNR_PAIR_ABLATE & 16) || o == 0) {
+            if constexpr (o == 0) pair_mfma_reb_first(R[c], x, W[c][0], P[0][1], P[1][1]);
+            else pair_mfma_reb(R[c], x, W[c][o]);
+          }
+        } else {
+          constexpr int e = ~o, t = e / NM, m = e % NM;
+          bf16x4 &lo = tl[arg % WIN], &hi = th[arg % WIN];
+          if constexpr (!FIRST) {
+            // (tools/check_lds_asm.py verifies on the listing that no VALU instruction writes an MFMA operand in the two
+            //  wait states in front of it: the compiler is free to assemble this tuple with moves)
+            const Frag fa = Frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if constexpr (!PB && c == 1) {
+              // bias gradient of layer 2k+1: this wave sums the rows of its two row tiles
+              if constexpr (!(SNR_PAIR_ABLATE & 128) && m / 2 == WV) pk_sum_bf16(bsum[m & 1], __builtin_bit_cast(u32x4, fa));
+            }
+            if constexpr (!(SNR_PAIR_ABLATE & 32) || m == 0) pair_mfma_acc(acc[c][m], fa, P[c][t]);
+          }
+        }
+        // nothing moves across an MFMA: what the schedule puts between two of them stays in that shadow (left alone, the
+        // compiler gathers the conversions in front of the body's first MFMA)
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (kind == EV_SYNC) {
+        // tile i+1 has landed (this wave's pieces: loads retire in order, RING - 3 younger tiles may be outstanding); behind
+        // the barrier that holds for everybody, and everybody is done with tile i-1: its slot can be refilled
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * NI) : "memory");
+#if !(SNR_PAIR_ABLATE & 4)
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");
+      } else if constexpr (kind == EV_CVT) {
+        constexpr int h = arg / 4, d = arg % 4;
+        if constexpr (d == 0) {
+          if constexpr (h == 0) pair_r_complete(R[0], R[1]);   // the rebuild's last MFMAs are only a step or two back
+          if constexpr (PB) {
+            constexpr int y = PG.young_flags(h, ei);
+            pair_wait<y>(fw[0][0], fw[0][1], fw[1][0], fw[1][1]);
+          }
+        }
+        convert_slice(std::integral_constant<int, h>{}, std::integral_constant<int, d>{});
+      } else if constexpr (kind == EV_DMA) {
+        issue_piece(islot, std::integral_constant<int, arg>{});
+      } else if constexpr (kind == EV_SUM) {
+        if constexpr (!FIRST) {
+          pk_sum_bf16(bsum[0], P[0][arg]);
+          pk_sum_bf16(bsum[1], P[1][arg]);
+        }
+      }
+    });
+    advance();
+    islot = islot + 1 == RING ? 0 : islot + 1;
+    slot = slot_next;
+    slot_next = slot_next + 1 == RING ? 0 : slot_next + 1;
+  };
+
+  // ---- prologue: tiles 0 .. RING-3 in flight, body -1 rebuilds tile 0 (and issues tile RING-2) ----
+  for (int d = 0; d < RING - 2; ++d) {
+    static_for<0, NI>([&](auto K_) { issue_piece(d, K_); });
+    advance();
+  }
+  body(std::true_type{});
+  for (int64_t tile = 0; tile < t1; ++tile) body(std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // trailing loads; last MFMA -> accumulator reads
+
+  // ---- partial sums: plane [256 columns][32 NM rows], bf16; lane (column, half gg) holds rows 8 k + 4 gg + 0..3 of every
+  // row tile in registers 4 k .. 4 k + 3: one 8-byte store each ----
+  constexpr int NB = 32 * NM;
+  __bf16* plane = (__bf16*)(a.part + H.part_off + (int64_t)split * 256 * NB);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int64_t col = 64 * wave + 32 * c + (lane & 31);
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bf16x4 h = {(__bf16)acc[c][m][4 * k], (__bf16)acc[c][m][4 * k + 1], (__bf16)acc[c][m][4 * k + 2], (__bf16)acc[c][m][4 * k + 3]};
+        *(bf16x4*)(plane + col * NB + 32 * m + 8 * k + 4 * gg) = h;
+      }
+  }
+  float* bp = a.part + H.bias_part_off + (int64_t)split * 256;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float bs = bsum[c] + __shfl_xor(bsum[c], 32, 64);
+    // kind A: row tile 2 wave + c of D (d z_{2k+1} slots); kind B: column block 2 wave + c (neurons of layer 2k)
+    if (lane < 32) bp[64 * wave + 32 * c + lane] = bs;
+  }
+}
+
+__global__ __launch_bounds__(64 * kPairWaves) void mlp_wgrad_pair_kernel(PairArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const int kind = (b >> 3) & 1;                 // workgroups b and b ^ 8 (same XCD) are the two kinds of one slot
+  const int p = (b >> 4) * 8 + (b & 7);
+  int ji = 0;
+  while (ji + 1 < a.n_pairs && a.job[ji + 1].slot_begin <= p) ++ji;
+  const PairJob& J = a.job[ji];
+  const int split = p - J.slot_begin;
+  if (split >= J.n_splits) return;               // (slots beyond the last job)
+  // kind A is compiled once per wave (its row sums), kind B once
+#define SNR_PAIR_A(KX_) \
+  do { \
+    if (wave == 0) pair_run<0, KX_, 0>(a, J, split, smem, wave, lane); \
+    else if (wave == 1) pair_run<0, KX_, 1>(a, J, split, smem, wave, lane); \
+    else if (wave == 2) pair_run<0, KX_, 2>(a, J, split, smem, wave, lane); \
+    else pair_run<0, KX_, 3>(a, J, split, smem, wave, lane); \
+  } while (0)
+#ifdef SNR_PAIR_ONLY   // register-allocation experiments: one instance per build
+  if (SNR_PAIR_ONLY == 0) pair_run<0, 16, 1>(a, J, split, smem, wave, lane);
+  if (SNR_PAIR_ONLY == 1) pair_run<1, 16, 0>(a, J, split, smem, wave, lane);
+  if (SNR_PAIR_ONLY == 2) pair_run<0, 4, 1>(a, J, split, smem, wave, lane);
+  if (SNR_PAIR_ONLY == 3) pair_run<1, 4, 0>(a, J, split, smem, wave, lane);
+  return;
+#endif
+  if (J.x_ks == 16) {
+    if (kind == 0) SNR_PAIR_A(16);
+    else pair_run<1, 16, 0>(a, J, split, smem, wave, lane);
+  } else {
+    if (kind == 0) SNR_PAIR_A(4);
+    else pair_run<1, 4, 0>(a, J, split, smem, wave, lane);
+  }
+#undef SNR_PAIR_A
+}
+
+}  // namespace snr
+
+namespace snr {
+
+// ------------------------------------------------------------------------------------------
+// host: the four layer pairs, their slots, and the reduce table of their partial sums
+// ------------------------------------------------------------------------------------------
+struct PairPlan {
+  PairArgs pa;          // kernel arguments (pointers still to be filled in)
+  WgradArgs red;        // reduce / scatter table over the pair kernel's partial planes (mlp_wgrad_reduce_kernel)
+  int grid;             // workgroups of the pair kernel
+  int64_t part_floats;  // floats of partial sums behind part_base
+};
+
+// part_base: floats of the partial-sum buffer already taken by the plain pass
+inline PairPlan make_pair_plan(const snr_mlp_config* c, int64_t n_samples, int64_t part_base) {
+  using B = Blob<kBF16>;
+  constexpr int SPF = 2 * Prec<kBF16>::EPF;
+  const int vd = c->use_viewdirs;
+  const ParamLayout L = make_param_layout(c->multires, c->multires_views, vd, c->out_ch, c->i_embed == -1);
+  const PackTable T = make_pack_table<kBF16>(c->multires, c->multires_views, vd, c->out_ch, c->i_embed == -1);
+  const ActLayout<kBF16> AL(n_samples, vd);
+  const WsLayout<kBF16> WL(n_samples, vd);
+  const int L_pts = c->i_embed == -1 ? 0 : c->multires;
+  const int ip = L.in_pts;
+  PairPlan Pl{};
+  PairArgs& A = Pl.pa;
+  WgradArgs& R = Pl.red;
+  A.n_pairs = kMaxPairs;
+  A.n_tiles = AL.n_tiles;
+  R.n_tiles = AL.n_tiles;
+  // slots: one kind-A and one kind-B workgroup each, all CUs busy; apportioned by the MFMAs per tile of a pair
+  // (pair 0 rebuilds from / accumulates against the 64-wide encoding: (8 + 32) + (32 + 8) of the (32 + 32) x 2 of the others)
+  int cus = 256;
+  {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    else (void)hipGetLastError();
+  }
+  int n_slots = cus / 2;
+  if (const char* e = getenv("SNR_PAIR_SLOTS")) n_slots = atoi(e) > 0 ? atoi(e) : n_slots;
+  if (n_slots < kMaxPairs) n_slots = kMaxPairs;
+  int w0 = 66;   // cost of pair 0 relative to 100 of the others
+  if (const char* e = getenv("SNR_PAIR_W0")) w0 = atoi(e) > 0 ? atoi(e) : w0;
+  const int wsum = w0 + 300;
+  int splits[kMaxPairs];
+  int used = 0;
+  for (int k = 0; k < kMaxPairs; ++k) {
+    splits[k] = n_slots * (k == 0 ? w0 : 100) / wsum;
+    if (splits[k] < 1) splits[k] = 1;
+    used += splits[k];
+  }
+  for (int k = kMaxPairs - 1; used < n_slots; k = k == 1 ? kMaxPairs - 1 : k - 1) { ++splits[k]; ++used; }   // left-overs to the heavy pairs
+  int slot = 0, nj = 0, no = 0;
+  int64_t po = part_base;
+  const int n_fwd_entries = 8 + (vd ? 4 : 1), n_top_bwd = vd ? 3 : 1;
+  for (int k = 0; k < kMaxPairs; ++k) {
+    PairJob& J = A.job[k];
+    const int la = 2 * k, lb = 2 * k + 1;   // rebuilt / accumulated layers: kind A rebuilds h_{la}, accumulates dW_{lb}
+    J.x_ks = k == 0 ? B::KS_PE : B::KS_H;
+    J.x_off = k == 0 ? AL.off_pe() : AL.off_h(la - 1);
+    J.dz_off = WL.off_dz(lb);
+    J.flag_off = AL.off_mask(la);
+    int64_t s = splits[k];
+    if (s > A.n_tiles) s = A.n_tiles;
+    J.slot_begin = slot; J.n_splits = (int)s; slot += (int)s;
+    const int NMb = J.x_ks / 2;
+    J.a.w_frag = T.e[la].frag_begin;
+    J.a.bias_off = bias_off_stage(la);
+    J.b.w_frag = T.e[n_fwd_entries + n_top_bwd + (7 - lb)].frag_begin;
+    J.b.bias_off = 0;
+    J.a.part_off = po; po += s * 256 * 256;
+    J.a.bias_part_off = po; po += s * 256;
+    J.b.part_off = po; po += s * 256 * 32 * NMb;
+    J.b.bias_part_off = po; po += s * 256;
+    // reduce table: kind A planes [column j of h_{la} (true order)][row = d z_{lb} slot] -> dW_{lb}[true(row)][j]
+    auto rjob = [&](int nta, int ntb, int64_t part_off, int64_t bias_part_off) {
+      WgradJob& Q = R.job[nj];
+      Q.nta = nta; Q.ntb = ntb; Q.n_splits = (int)s; Q.split_begin = 0; Q.part_off = part_off; Q.bias_part_off = bias_part_off;
+      return nj++;
+    };
+    auto rout = [&](int j, int rows, int a_kind, int cols, int b_kind, int Lenc, int64_t w_off, int ld, int col_off,
+                    int rows_valid, int cols_valid, int64_t bias_off, int transposed) {
+      WgradOut& O = R.out[no++];
+      O.job = j; O.row0 = 0; O.rows = rows; O.a_kind = a_kind; O.col0 = 0; O.cols = cols; O.b_kind = b_kind; O.L = Lenc;
+      O.w_off = (int)w_off; O.ld = ld; O.col_off = col_off; O.row_off = 0; O.rows_valid = rows_valid; O.cols_valid = cols_valid;
+      O.bias_off = (int)bias_off; O.to_scratch = 0; O.transposed = transposed;
+    };
+    const int ld_b = lb == kSkip + 1 ? kW + ip : kW, co_b = lb == kSkip + 1 ? ip : 0;
+    int j = rjob(8, 8, J.a.part_off, J.a.bias_part_off);
+    rout(j, kW, SRC_NAT, kW, SRC_H, 0, L.w_pts[lb], ld_b, co_b, kW, kW, -1, 1);
+    j = rjob(8, 0, J.a.part_off, J.a.bias_part_off);   // its row sums of d z_{lb}: the bias gradient, indexed by the slot order
+    rout(j, 8 * 2 * SPF, SRC_H, 0, SRC_H, 0, 0, 0, 0, kW, 0, L.b_pts[lb], 0);
+    // kind B planes [neuron n of layer la (true order)][row = X slot] -> dW_{la}[n][true(row)], column sums -> db_{la}
+    j = rjob(8, NMb, J.b.part_off, J.b.bias_part_off);
+    if (k == 0) rout(j, kW, SRC_NAT, 32 * NMb, SRC_ENC_PTS, L_pts, L.w_pts[la], ip, 0, kW, ip, L.b_pts[la], 0);
+    else rout(j, kW, SRC_NAT, 32 * NMb, SRC_H, 0, L.w_pts[la], kW, 0, kW, kW, L.b_pts[la], 0);
+  }
+  R.n_jobs = nj; R.n_outs = no;
+  Pl.grid = 16 * ((slot + 7) / 8);   // slot p = workgroups 16 (p / 8) + p % 8 and + 8
+  Pl.part_floats = po - part_base;
+  return Pl;
+}
+
+}  // namespace snr

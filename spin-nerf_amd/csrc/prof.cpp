@@ -16,7 +16,7 @@ hipEvent_t g_open_a = nullptr;
 int g_open_id = -1;
 const char* kNames[K_COUNT] = {"mlp_pack", "mlp_fwd", "mlp_dgrad", "mlp_wgrad", "mlp_wgrad_reduce", "sample_coarse",
                                "composite_fwd", "composite_bwd", "sample_fine", "make_rays", "adam", "hg_pack", "hg_fwd",
-                               "hg_bwd"};
+                               "hg_bwd", "mlp_wgrad_pair"};
 hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;

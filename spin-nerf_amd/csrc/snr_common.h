@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <atomic>
 
@@ -43,6 +44,14 @@ template <auto Kernel> inline int ensure_dynamic_lds(int bytes) {
   if (e != hipSuccess) return (int)e;
   done.fetch_or(bit, std::memory_order_release);
   return 0;
+}
+
+// bf16 training saves only the odd hidden layers / odd d z and rebuilds the even ones inside the weight-gradient pass
+// (mlp_wgrad_pair.h).  SNR_RECOMPUTE=0 selects the plain pass (every layer saved) for A/B measurements; the forward and
+// the backward of one step must see the same setting.
+inline bool recompute_enabled() {
+  const char* e = getenv("SNR_RECOMPUTE");
+  return !(e && e[0] == '0');
 }
 
 // ---- MFMA policies --------------------------------------------------------------------------

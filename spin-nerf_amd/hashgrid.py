@@ -148,7 +148,8 @@ class NeRF_TCNN(nn.Module):
         viewdirs = viewdirs.detach()
         if viewdirs.dtype != torch.float32 or viewdirs.stride(-1) != 1:
             viewdirs = f32c(viewdirs)
-        return _HashGrid.apply(self.flat, self, pts, rays, z_vals, viewdirs, M, S)
+        flat = self.flat if torch.is_grad_enabled() else self.flat.detach()   # no_grad: inference kernel, nothing saved
+        return _HashGrid.apply(flat, self, pts, rays, z_vals, viewdirs, M, S)
 
     # ---- the autograd-free training step (train.py: _step_direct; same contract as ops.mlp_train_forward / _backward) --
     def train_forward(self, rays, z_vals, viewdirs):

@@ -348,7 +348,10 @@ def mlp_query(net, pts=None, rays=None, z_vals=None, viewdirs=None, samples_per_
             viewdirs = f32c(viewdirs)
     else:
         viewdirs = None
-    return _Mlp.apply(net.flat, net, pts, rays, z_vals, viewdirs, M, samples_per_ray)
+    # Function.forward always runs with grad mode off, and needs_input_grad stays True under torch.no_grad(): a detached
+    # buffer is what tells it that this evaluation saves nothing (inference kernel, no activation workspace)
+    flat = net.flat if torch.is_grad_enabled() else net.flat.detach()
+    return _Mlp.apply(flat, net, pts, rays, z_vals, viewdirs, M, samples_per_ray)
 
 
 # ----------------------------------------------------------------------------------------------
