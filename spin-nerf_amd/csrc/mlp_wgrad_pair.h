@@ -59,6 +59,7 @@ struct PairArgs {
   const float* bias;     // bias block inside the blob
   float* part;
   int64_t n_tiles;
+  int only_kind, only_pair;   // timing experiments (SNR_PAIR_KIND / SNR_PAIR_PAIR): -1 = all
 };
 
 constexpr int kPairWaves = 4;
@@ -71,15 +72,20 @@ constexpr int kPairWaves = 4;
 // tile i+1.  Its MFMAs come in operand STEPS of two (the wave's two column blocks share the A operand):
 //   R-step q     one fragment of tile i+1's rebuild section (ds_read_b128)             R[c] += frag x W[c][q]
 //   A-step (m,t) row tile m, k-step t of tile i's accumulation section (2 transposing reads)   acc[c][m] += frag x P[c][t]
-// Order: the first A-steps of k-step 0 lead (their reads were issued by the previous body, nothing in them depends on the
-// barrier), the barrier that publishes tile i+1 follows step 0, then R-steps and the remaining A-steps alternate, and the
-// last A-steps of k-step 1 trail the last R-step.  Under the leading steps the upper half of the previous rebuild (C
-// registers 8..15 = k-step 1's operand) is converted, under the trailing steps the lower half of the new one (k-step 0's
-// operand of the next body) — the k-step whose registers have just been used up; only the 16 cvt + finishing
-// instructions per half ever sit between two MFMAs.  Every LDS read is issued LA steps ahead of its MFMAs (R-steps: not
-// before the barrier), across the loop's back edge for the leading steps.  Completion is counted: LDS operations retire in
-// order, so the wait in front of a step allows exactly the reads issued since its own (PairProg::young).
-enum { EV_ISSUE = 0, EV_FLAGS, EV_STEP_A, EV_STEP_B, EV_CVT, EV_SYNC, EV_DMA, EV_SUM };
+// One wave per SIMD issues in order, so whatever sits between two MFMAs runs in the 32-cycle shadow of the first one
+// and no further: tests/probes/mfma_agpr.hip measures 4 other instructions per MFMA as free, 5 as +20 %, 6 as +50 %.
+// The ~230 non-MFMA instructions of a body are therefore PLACED, at most about four to a gap (nothing moves across an
+// MFMA: sched_barrier), in this order:
+//   head    all A-steps of k-step 0 (their reads were issued by the previous body; nothing in them needs the barrier,
+//           which follows step 0).  In their gaps: the upper half of the previous rebuild (C registers 8..15 = k-step 1's
+//           operand, whose registers the previous body used up last) is converted, one packed word per gap.
+//   middle  all R-steps; in their gaps the DMA pieces of tile i+RING-1, the pointer updates, kind B's column sums.
+//   tail    all A-steps of k-step 1; in their gaps the lower half of the new rebuild is converted into k-step 0's
+//           operand registers (free since the head) — the next body starts on it at once.
+// Every LDS read is issued LA steps ahead of its MFMAs, across the loop's back edge for the head.  Completion is counted:
+// LDS operations retire in order, so the wait in front of an even step (it covers the odd step behind it too) allows
+// exactly the reads issued since (PairProg::young_pair).
+enum { EV_ISSUE = 0, EV_FLAGS, EV_STEP_A, EV_STEP_B, EV_CVT, EV_SYNC, EV_DMA, EV_SUM, EV_SUMA, EV_ADVANCE };
 template <int TYPE, int KX> struct PairCfg {
   static constexpr bool PB = TYPE == 1;
   static constexpr int KR = PB ? 16 : KX;        // fragments of the rebuild's contraction
@@ -96,14 +102,14 @@ template <int TYPE, int KX> struct PairCfg {
   static constexpr int LA = 4;                   // operand steps the LDS reads run ahead of their MFMAs
   static constexpr int WIN = NS % 8 == 0 ? 8 : 5;   // operand register sets, step s uses set s % WIN (a divisor of NS, > LA;
                                                  // only the LA + 1 sets with reads in flight are live)
-  static constexpr int LEADA = NM < 4 ? NM : 4;  // k-step 0 A-steps in front (step 0 ahead of the barrier)
-  static constexpr int TAILA = NM < 4 ? NM : 4;  // k-step 1 A-steps behind the last R-step
+  static constexpr int LEADA = NM;               // head: the A-steps of k-step 0 (step 0 ahead of the barrier)
+  static constexpr int TAILA = NM;               // tail: the A-steps of k-step 1
   static constexpr int SYNC_STEP = 0;            // the barrier follows this step
 };
 
 template <int TYPE, int KX> struct PairProg {
   using C = PairCfg<TYPE, KX>;
-  static constexpr int NS = C::NS, NM = C::NM, NR = C::NR, LA = C::LA, MAXEV = 4 * C::NS + 32;
+  static constexpr int NS = C::NS, NM = C::NM, NR = C::NR, LA = C::LA, MAXEV = 6 * C::NS + 64;
   int order[NS];   // >= 0: R-step q;  < 0: A-step ~e, e = t * NM + m
   int ip[NS];      // position (= "in front of step ip") at which the step's reads are issued; < 0: NS + ip of the previous body
   int kind[MAXEV], arg[MAXEV], nxt[MAXEV], n;
@@ -129,32 +135,53 @@ template <int TYPE, int KX> struct PairProg {
       ip[i] = i - LA;
       if (order[i] >= 0 && ip[i] < C::SYNC_STEP + 1) ip[i] = C::SYNC_STEP + 1;   // rebuild reads: behind the barrier
     }
-    // ---- events ----
-    // A step is [wait (even steps: for this step and the next)] MFMA a | reads for later steps, a slice of conversion work |
-    // MFMA b | DMA piece: the wave issues in order, so what sits between the two MFMAs runs in the shadow of the first and
-    // what follows the second in the shadow of the second.  The two conversions (upper half of the previous rebuild under
-    // the leading A-steps, lower half of the new one under the trailing A-steps) are cut into four slices of one packed
-    // word per column block each.
-    const int first_tail = NS - C::TAILA, n_head = first_rstep();
+    // ---- events: step p = MFMA a | gap 2p | MFMA b | gap 2p+1 ----
+    // gap 2p holds the reads issued at position p; the odd gaps hold everything else.  The 8 conversion items of a half
+    // (packed word d = j / 2 of column block c = j % 2) go one to an odd gap of the head (upper half) / tail (lower half)
+    // when there are 8 steps, else evenly over all of its gaps.
+    const int first_tail = NS - C::TAILA, G = 2 * NS;
+    const int hi_gaps = 2 * C::LEADA - 1;            // gaps 0 .. hi_gaps-1 precede the first R-step's first MFMA
+    const int lo_gap0 = 2 * first_tail + 1;          // first gap behind the tail's first step (two MFMAs behind the last R MFMA)
+    const int lo_gaps = G - lo_gap0;
+    const int dma_step0 = C::LEADA;                  // DMA pieces: behind MFMA b of the middle's steps
+    const int adv_step0 = dma_step0 + C::NI;         // then the pointer updates (3 parts), then kind B's column sums (4 parts)
+    // Top of the body, in front of the first MFMA: the reads of the leading steps and of kind B's k-step-1 flag words, then
+    // the first conversion items (they need no LDS data: the wait for the reads falls behind them).  No asm read is ever in
+    // flight across the loop's back edge or at its exit: for the compiler such a read is complete when issued, and a copy it
+    // places at a loop boundary (or a reuse of the register behind the loop) would meet the old register content.
+    const int n_top = C::PB ? 4 : 6;                 // conversion micro-items at the top
+    if (C::PB) { push(EV_FLAGS, 2, 0); push(EV_FLAGS, 3, 0); }
+    for (int i = 0; i < NS; ++i) if (ip[i] < 0) push(EV_ISSUE, i, 0);
+    for (int u = 0; u < n_top; ++u) push(EV_CVT, 16 * 1 + u, 0);
     for (int p = 0; p < NS; ++p) {
       push(EV_STEP_A, p, 0);
-      for (int i = 0; i < NS; ++i) if (ip[i] == p) push(EV_ISSUE, i, 0);
-      for (int i = 0; i < NS; ++i) if (ip[i] < 0 && ip[i] + NS == p) push(EV_ISSUE, i, 1);
-      if (C::PB && p == first_tail - 2) push(EV_FLAGS, 0, 1);   // flags of the next tile's k-step 0: used by the tail's slices
-      for (int d = 0; d < 4; ++d) {
-        if (p < n_head && d * n_head / 4 == p) push(EV_CVT, 4 * 1 + d, 0);                              // upper half, slice d
-        if (p >= first_tail && d * C::TAILA / 4 == p - first_tail) push(EV_CVT, 4 * 0 + d, 0);          // lower half, slice d
+      for (int half = 0; half < 2; ++half) {         // gap 2p (half 0), then MFMA b, then gap 2p+1 (half 1)
+        const int g = 2 * p + half;
+        if (half == 0) {
+          // (... second half — in front of this gap's reads: with WIN = LA + 1 the reads of step p + LA reuse the registers of step p - 1)
+          if (p > 0 && order[p - 1] < 0 && !C::PB) push(EV_SUMA, 2 * (p - 1) + 1, 0);
+          for (int i = 0; i < NS; ++i) if (ip[i] == p) push(EV_ISSUE, i, 0);
+        } else {
+          push(EV_STEP_B, p, 0);
+          if (p == C::SYNC_STEP) push(EV_SYNC, 0, 0);
+          if (order[p] < 0 && !C::PB) push(EV_SUMA, 2 * p, 0);   // kind A: row sums of this A-step's operand (if the wave owns the rows),
+          if (p >= dma_step0 && p < adv_step0) push(EV_DMA, p - dma_step0, 0);
+          if (p >= adv_step0 && p < adv_step0 + 4) push(EV_ADVANCE, p - adv_step0, 0);
+          if (C::PB && p >= adv_step0 + 4 && p < adv_step0 + 8) push(EV_SUM, p - (adv_step0 + 4), 0);
+          if (C::PB && p == first_tail - 1) { push(EV_FLAGS, 0, 1); push(EV_FLAGS, 1, 1); }   // next tile's k-step 0 flags: the tail's conversion
+        }
+        // 16 conversion micro-items per half of R: item j = 2 d + c (packed word d of column block c), part 0 (add / convert)
+        // and part 1 (relu | flags) in different gaps, spread evenly
+        if (g == G - 1 && order[NS - 1] < 0 && !C::PB) push(EV_SUMA, 2 * (NS - 1) + 1, 0);
+        for (int u = 0; u < 16; ++u) {
+          if (u >= n_top && (u - n_top) * hi_gaps / (16 - n_top) == g && g < hi_gaps) push(EV_CVT, 16 * 1 + u, 0);
+          if (lo_gap0 + u * lo_gaps / 16 == g) push(EV_CVT, 16 * 0 + u, 0);
+        }
       }
-      if (C::PB && p == NS - 1) push(EV_FLAGS, 1, 1);           // ... k-step 1: by the next body's leading slices
-      if (C::PB && p == n_head - 1) push(EV_SUM, 1, 0);
-      push(EV_STEP_B, p, 0);
-      if (p == C::SYNC_STEP) push(EV_SYNC, 0, 0);
-      if (p > C::SYNC_STEP && p - C::SYNC_STEP - 1 < C::NI) push(EV_DMA, p - C::SYNC_STEP - 1, 0);
-      if (C::PB && p == 0) push(EV_SUM, 0, 0);
     }
   }
   constexpr int reads_of(int e) const {
-    return kind[e] == EV_ISSUE ? (order[arg[e]] >= 0 ? 1 : 2) : (kind[e] == EV_FLAGS ? 4 : 0);
+    return kind[e] == EV_ISSUE ? (order[arg[e]] >= 0 ? 1 : 2) : (kind[e] == EV_FLAGS ? 2 : 0);
   }
   // LDS reads issued behind event `issue` and in front of event `use` (cyclically, when the issue belongs to the previous body)
   constexpr int between(int issue, int use) const {
@@ -180,7 +207,7 @@ template <int TYPE, int KX> struct PairProg {
       if (t == 0 && i >= NS - C::TAILA) return false;
       if (t == 1 && i <= C::SYNC_STEP) return false;
     }
-    return n <= MAXEV && C::SYNC_STEP + 1 + C::NI <= NS;
+    return n <= MAXEV && (C::PB ? C::LEADA + C::NI + 8 <= NS - C::TAILA + 1 : C::LEADA + C::NI + 4 <= NS) && first_rstep() == C::LEADA;
   }
 };
 
@@ -209,6 +236,9 @@ template <int N> __device__ __forceinline__ void pair_wait(bf16x8& a, bf16x4& b,
 }
 template <int N> __device__ __forceinline__ void pair_wait(bf16x4& a, bf16x4& b, bf16x4& c, bf16x4& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(SNR_PAIR_LGKM(N)));
+}
+template <int N> __device__ __forceinline__ void pair_wait(u32x4& a, u32x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(SNR_PAIR_LGKM(N)));
 }
 template <int N> __device__ __forceinline__ void pair_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(SNR_PAIR_LGKM(N)));
@@ -243,11 +273,16 @@ __device__ __forceinline__ void pair_operand_ready(u32x4& b0, u32x4& b1) { asm v
 // work in place: left to the compiler the 16 words of a k-step are expanded into several dozen temporaries at once, and
 // the weight fragments are spilled to make room.
 //   keep the low / high bf16 of x where bit `bit` of w0 / w1 (the two samples' flag words) is set; w0, w1 are consumed
-__device__ __forceinline__ void pk_and_flags(unsigned& x, unsigned& w0, unsigned& w1, unsigned bit) {
-  asm("v_bfe_i32 %1, %1, %3, 1\n\tv_bfe_i32 %2, %2, %3, 1\n\tv_bfi_b32 %1, %4, %1, %2\n\tv_and_b32 %0, %0, %1"
-      : "+v"(x), "+v"(w0), "+v"(w1) : "v"(bit), "s"(0xffffu));
+__device__ __forceinline__ void pk_flags_extract(unsigned& w0, unsigned& w1, unsigned bit) {   // -> 0 / -1 each
+  asm("v_bfe_i32 %0, %0, %2, 1\n\tv_bfe_i32 %1, %1, %2, 1" : "+v"(w0), "+v"(w1) : "v"(bit));
+}
+__device__ __forceinline__ void pk_flags_apply(unsigned& x, unsigned& m0, unsigned m1) {   // low half by m0, high half by m1
+  asm("v_bfi_b32 %1, %3, %1, %2\n\tv_and_b32 %0, %0, %1" : "+v"(x), "+v"(m0) : "v"(m1), "s"(0xffffu));
 }
 //   sum += low bf16 + high bf16 of x  (v_dot2c_f32_bf16 against (1, 1): one instruction per word)
+__device__ __forceinline__ void pk_sum_bf16_2(float& sum, unsigned x0, unsigned x1) {
+  asm("v_dot2c_f32_bf16 %0, %3, %1\n\tv_dot2c_f32_bf16 %0, %3, %2" : "+v"(sum) : "v"(x0), "v"(x1), "s"(0x3f803f80u));
+}
 //   (four words per statement: the compiler pads every asm statement whose output the next instruction reads)
 __device__ __forceinline__ void pk_sum_bf16(float& sum, const u32x4& x) {
   asm("v_dot2c_f32_bf16 %0, %5, %1\n\tv_dot2c_f32_bf16 %0, %5, %2\n\tv_dot2c_f32_bf16 %0, %5, %3\n\tv_dot2c_f32_bf16 %0, %5, %4"
@@ -280,20 +315,52 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
   const int fd = 64 * wave + lane;
   const uint32_t f_lane = (uint32_t)((((fd >> 7) * 32 + (fd & 31)) * 4 + ((fd >> 5) & 3)) * 4);
   int64_t issued = 0;   // tiles issued so far
+  bool go = false;
+  // One statement per piece: M0 = LDS destination of the wave's 1 KiB (the hardware adds lane x 16), a wait state, the
+  // load with a wave-uniform 64-bit base + a 32-bit lane offset (lane16 + 4096 k lives in four registers: no address
+  // arithmetic per piece).  M0 is written in the statement that reads it (the compiler does not preserve it around asm);
+  // the scalar add clobbers SCC, which the compiler may hold live across the statement (found as intermittent garbage).
+  // (No LDS read may sit in the cycle in front of an LDS-DMA — mlp_device.h, Pipe::issue_one: the schedule places every
+  //  piece behind a step's second MFMA, the prologue's behind nothing.)
+  uint32_t voff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) voff[k] = lane16 + 4096u * k;
+  const uint32_t lds_w = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);
+  // (the flag KiB: four bytes per lane, gathered into the [g][word][s] image; this wave's quarter starts 256 wave bytes in:
+  //  lds_w holds 1024 wave)
+  const uint32_t flag_w = C::FO - 768 * wave;
+  auto issue_flags = [&](uint32_t sl) {
+    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %3" :: "v"(f_lane), "s"(sl), "s"(flag_w), "s"(fp) : "scc");
+  };
   auto issue_piece = [&](int slot, auto K_) {
     constexpr int k = decltype(K_)::value;
-    char* sbase = smem + slot * SLOT;
+    const uint32_t sl = lds_w + slot * SLOT;
 #if SNR_PAIR_ABLATE & 1
     if (issued > 2 * RING) return;
 #endif
-    // (no LDS read may sit in the cycle in front of an LDS-DMA — mlp_device.h, Pipe::issue_one: the schedule places every
-    //  DMA piece behind a step's MFMAs, and the prologue's behind nothing)
+#ifdef SNR_PAIR_DMA_BUILTIN
+    char* sbase = smem + slot * SLOT;
     if constexpr (k < C::NIX) {
       __builtin_amdgcn_global_load_lds(xp + 4096 * k + lane16, SNR_LDS(sbase + C::XO + (wave + 4 * k) * 1024), 16, 0, 0);
     } else if constexpr (k < C::NIX + C::NID) {
       __builtin_amdgcn_global_load_lds(dp + 4096 * (k - C::NIX) + lane16, SNR_LDS(sbase + C::DZO + (wave + 4 * (k - C::NIX)) * 1024), 16, 0, 0);
     } else if constexpr (PB && k == C::NIX + C::NID) {
       __builtin_amdgcn_global_load_lds(fp + f_lane, SNR_LDS(sbase + C::FO + wave * 256), 4, 0, 0);
+    }
+    return;
+#endif
+    if constexpr (k < C::NIX) {
+      asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+                   :: "v"(voff[k]), "s"(sl), "n"(C::XO + 4096 * k), "s"(xp) : "scc");
+    } else if constexpr (k < C::NIX + C::NID) {
+      asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+                   :: "v"(voff[k - C::NIX]), "s"(sl), "n"(C::DZO + 4096 * (k - C::NIX)), "s"(dp) : "scc");
+    } else if constexpr (PB && k == C::NIX + C::NID) {
+#ifdef SNR_PAIR_FLAGS_BUILTIN
+      __builtin_amdgcn_global_load_lds(fp + f_lane, SNR_LDS(smem + slot * SLOT + C::FO + wave * 256), 4, 0, 0);
+#else
+      issue_flags(sl);
+#endif
     }
   };
   auto advance = [&]() {   // past the end the last tile is loaded again: every body issues the same NI instructions
@@ -366,36 +433,42 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
 
   int slot = RING - 1, slot_next = 0, islot = RING - 2;   // body -1: "tile -1" lives in the (empty) last slot
 
-  // slice d of half h of R -> packed word d of P[.][h] (+ bias, relu | flags): two C registers per column block
-  auto convert_slice = [&](auto H_, auto D_) {
-    constexpr int h = decltype(H_)::value, d = decltype(D_)::value;
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    // (the two column blocks side by side: a packed fp32 add needs a wait state in front of its consumer)
-    f32x2_t v[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      v[c] = f32x2_t{R[c][8 * h + 2 * d], R[c][8 * h + 2 * d + 1]};
-      if constexpr (!PB) v[c] += f32x2_t{bias_j[c], bias_j[c]};
-    }
-    unsigned x[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) x[c] = __builtin_bit_cast(unsigned, __builtin_convertvector(v[c], bf16x2_t));
-#if !(SNR_PAIR_ABLATE & 8)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      if constexpr (PB) {
-        // C registers 8 h + 2 d, + 1: quad (d >> 1) of this k-step's flag words, words 2 (d & 1), + 1 of it
-        unsigned w0 = fw[c][d >> 1][2 * (d & 1)], w1 = fw[c][d >> 1][2 * (d & 1) + 1];
-        pk_and_flags(x[c], w0, w1, fl_bit[c]);
+  // conversion item (h, d, c): C registers 8 h + 2 d, + 1 of column block c -> packed word d of P[c][h]; part 0 = bias add
+  // (kind A) | convert + flag bits to masks (kind B), part 1 = convert + relu (kind A) | apply the masks (kind B)
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t cv = {0.f, 0.f};
+  auto convert_item = [&](auto H_, auto D_, auto C_, auto PART_) {
+    constexpr int h = decltype(H_)::value, d = decltype(D_)::value, c = decltype(C_)::value, part = decltype(PART_)::value;
+    if constexpr (!PB) {
+      if constexpr (part == 0) {
+        cv = f32x2_t{R[c][8 * h + 2 * d], R[c][8 * h + 2 * d + 1]} + f32x2_t{bias_j[c], bias_j[c]};
       } else {
-        x[c] = pk_relu_bf16(x[c]);
+        unsigned x = __builtin_bit_cast(unsigned, __builtin_convertvector(cv, bf16x2_t));
+#if !(SNR_PAIR_ABLATE & 8)
+        x = pk_relu_bf16(x);
+#endif
+        P[c][h][d] = x;
+      }
+    } else {
+      // quad (d >> 1) of this k-step's flag words, words 2 (d & 1), + 1 of it (consumed in place)
+      unsigned w0 = fw[c][d >> 1][2 * (d & 1)], w1 = fw[c][d >> 1][2 * (d & 1) + 1];
+      if constexpr (part == 0) {
+        const f32x2_t v = f32x2_t{R[c][8 * h + 2 * d], R[c][8 * h + 2 * d + 1]};
+        P[c][h][d] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+#if !(SNR_PAIR_ABLATE & 8)
+        pk_flags_extract(w0, w1, fl_bit[c]);
+        fw[c][d >> 1][2 * (d & 1)] = w0; fw[c][d >> 1][2 * (d & 1) + 1] = w1;
+#endif
+      } else {
+#if !(SNR_PAIR_ABLATE & 8)
+        unsigned x = P[c][h][d];
+        pk_flags_apply(x, w0, w1);
+        P[c][h][d] = x;
+#endif
       }
     }
-#endif
-    P[0][h][d] = x[0];
-    P[1][h][d] = x[1];
-    if constexpr (d == 3) pair_operand_ready(P[0][h], P[1][h]);
+    if constexpr (d == 3 && c == 1 && part == 1) pair_operand_ready(P[0][h], P[1][h]);
   };
 
   // One body.  FIRST = body -1: rebuilds tile 0, accumulates nothing.
@@ -416,13 +489,11 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
           tr_read<m * 2048 + t * 512 + 256>(th[arg % WIN], nxt ? aTn : aT);
         }
       } else if constexpr (kind == EV_FLAGS) {
-        // flags of the NEXT tile (its slot holds them since this body's barrier), quads 2 t, 2 t + 1 of both column blocks
+        // flag words of k-step t = arg / 2, quad arg % 2 (C registers 8 t + 4 quad + 0..3), both column blocks: k-step 0's belong to
+        // the NEXT tile (the rebuild this body finishes; its slot holds them since the barrier), k-step 1's to this body's tile
+        constexpr int t = arg / 2, quad = arg % 2;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const uint32_t fa = sN + fl_addr[c];
-          pair_read16u<64 * arg>(fw[c][0], fa);
-          pair_read16u<64 * arg + 32>(fw[c][1], fa);
-        }
+        for (int c = 0; c < 2; ++c) pair_read16u<64 * t + 32 * quad>(fw[c][quad], (nxt ? sN : sA) + fl_addr[c]);
       } else if constexpr (kind == EV_STEP_A || kind == EV_STEP_B) {
         constexpr int o = PG.order[arg];
         constexpr int c = kind == EV_STEP_B ? 1 : 0;   // the column block of this MFMA
@@ -448,10 +519,6 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
             // (tools/check_lds_asm.py verifies on the listing that no VALU instruction writes an MFMA operand in the two
             //  wait states in front of it: the compiler is free to assemble this tuple with moves)
             const Frag fa = Frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if constexpr (!PB && c == 1) {
-              // bias gradient of layer 2k+1: this wave sums the rows of its two row tiles
-              if constexpr (!(SNR_PAIR_ABLATE & 128) && m / 2 == WV) pk_sum_bf16(bsum[m & 1], __builtin_bit_cast(u32x4, fa));
-            }
             if constexpr (!(SNR_PAIR_ABLATE & 32) || m == 0) pair_mfma_acc(acc[c][m], fa, P[c][t]);
           }
         }
@@ -467,28 +534,45 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
 #endif
         asm volatile("" ::: "memory");
       } else if constexpr (kind == EV_CVT) {
-        constexpr int h = arg / 4, d = arg % 4;
-        if constexpr (d == 0) {
-          if constexpr (h == 0) pair_r_complete(R[0], R[1]);   // the rebuild's last MFMAs are only a step or two back
-          if constexpr (PB) {
-            constexpr int y = PG.young_flags(h, ei);
-            pair_wait<y>(fw[0][0], fw[0][1], fw[1][0], fw[1][1]);
-          }
+        constexpr int h = arg / 16, j = (arg % 16) / 2, part = arg % 2, d = j / 2, c = j % 2;
+        static_assert(d < 4 && h < 2, "conversion item out of range");
+        if constexpr (j == 0 && part == 0) {
+          if constexpr (h == 0) pair_r_complete(R[0], R[1]);   // the rebuild's last MFMAs are only a step back
         }
-        convert_slice(std::integral_constant<int, h>{}, std::integral_constant<int, d>{});
+        if constexpr (PB && c == 0 && d % 2 == 0 && part == 0) {   // the quad of flag words this item and the next three use
+          constexpr int y = PG.young_flags(2 * h + d / 2, ei);
+          pair_wait<y>(fw[0][d / 2], fw[1][d / 2]);
+        }
+        convert_item(std::integral_constant<int, h>{}, std::integral_constant<int, d>{}, std::integral_constant<int, c>{},
+                     std::integral_constant<int, part>{});
+        __builtin_amdgcn_sched_barrier(0);
       } else if constexpr (kind == EV_DMA) {
         issue_piece(islot, std::integral_constant<int, arg>{});
       } else if constexpr (kind == EV_SUM) {
-        if constexpr (!FIRST) {
-          pk_sum_bf16(bsum[0], P[0][arg]);
-          pk_sum_bf16(bsum[1], P[1][arg]);
+        if constexpr (!FIRST) pk_sum_bf16(bsum[arg % 2], P[arg % 2][arg / 2]);   // (k-step arg / 2, column block arg % 2)
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (kind == EV_SUMA) {
+        // kind A, bias gradient of layer 2k+1: the wave sums the rows of its two row tiles (the step's operand registers are
+        // not reused before the reads of step + WIN are issued, LA - WIN steps from here)
+        constexpr int st = arg / 2, part = arg % 2;
+        constexpr int o = PG.order[st];
+        constexpr int m = (~o) % NM;
+        if constexpr (!FIRST && !(SNR_PAIR_ABLATE & 128) && m / 2 == WV) {
+          bf16x4 &lo = tl[st % WIN], &hi = th[st % WIN];
+          const u32x4 w = __builtin_bit_cast(u32x4, Frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+          pk_sum_bf16_2(bsum[m & 1], w[2 * part], w[2 * part + 1]);
+          __builtin_amdgcn_sched_barrier(0);
         }
+      } else if constexpr (kind == EV_ADVANCE) {
+        // all pieces of this body are issued: the pointers and the ring positions move on (the addresses of this body's
+        // reads were formed at its top)
+        if constexpr (arg == 0) { go = issued + 1 < t1; issued += go ? 1 : 0; }
+        if constexpr (arg == 1) { xp += go ? xs : 0; dp += go ? dst_ : 0; }
+        if constexpr (arg == 2) { fp += go ? fs_ : 0; islot = islot + 1 == RING ? 0 : islot + 1; }
+        if constexpr (arg == 3) { slot = slot_next; slot_next = slot_next + 1 == RING ? 0 : slot_next + 1; }
+        __builtin_amdgcn_sched_barrier(0);
       }
     });
-    advance();
-    islot = islot + 1 == RING ? 0 : islot + 1;
-    slot = slot_next;
-    slot_next = slot_next + 1 == RING ? 0 : slot_next + 1;
   };
 
   // ---- prologue: tiles 0 .. RING-3 in flight, body -1 rebuilds tile 0 (and issues tile RING-2) ----
@@ -498,7 +582,8 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
   }
   body(std::true_type{});
   for (int64_t tile = 0; tile < t1; ++tile) body(std::false_type{});
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // trailing loads; last MFMA -> accumulator reads
+  // trailing DMA loads; 12+ wait states from the last MFMA to the accumulator reads
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
   // ---- partial sums: plane [256 columns][32 NM rows], bf16; lane (column, half gg) holds rows 8 k + 4 gg + 0..3 of every
   // row tile in registers 4 k .. 4 k + 3: one 8-byte store each ----
@@ -536,6 +621,7 @@ __global__ __launch_bounds__(64 * kPairWaves) void mlp_wgrad_pair_kernel(PairArg
   const PairJob& J = a.job[ji];
   const int split = p - J.slot_begin;
   if (split >= J.n_splits) return;               // (slots beyond the last job)
+  if ((a.only_kind >= 0 && kind != a.only_kind) || (a.only_pair >= 0 && ji != a.only_pair)) return;
   // kind A is compiled once per wave (its row sums), kind B once
 #define SNR_PAIR_A(KX_) \
   do { \
@@ -591,6 +677,8 @@ inline PairPlan make_pair_plan(const snr_mlp_config* c, int64_t n_samples, int64
   WgradArgs& R = Pl.red;
   A.n_pairs = kMaxPairs;
   A.n_tiles = AL.n_tiles;
+  A.only_kind = getenv("SNR_PAIR_KIND") ? atoi(getenv("SNR_PAIR_KIND")) : -1;
+  A.only_pair = getenv("SNR_PAIR_PAIR") ? atoi(getenv("SNR_PAIR_PAIR")) : -1;
   R.n_tiles = AL.n_tiles;
   // slots: one kind-A and one kind-B workgroup each, all CUs busy; apportioned by the MFMAs per tile of a pair
   // (pair 0 rebuilds from / accumulates against the 64-wide encoding: (8 + 32) + (32 + 8) of the (32 + 32) x 2 of the others)
