@@ -212,7 +212,9 @@ int snr::wgrad_launch_bf16(const WgradArgs& w, int total_splits, float* grad, in
   const int per_out = 4 * 256 * (256 / 4 + 1);   // 4 lanes per (row, 4-column group | bias) item
   {
     ProfScope ps(K_MLP_WGRAD_REDUCE, s);
-    mlp_wgrad_reduce_kernel<kBF16><<<dim3((per_out + 255) / 256, (unsigned)w.n_outs), dim3(256), 0, s>>>(w, grad, accumulate);
+    ReduceArgs ra{};
+    append_reduce(ra, w);
+    mlp_wgrad_reduce_kernel<kBF16><<<dim3((per_out + 255) / 256, (unsigned)ra.n_outs), dim3(256), 0, s>>>(ra, grad, accumulate);
   }
   return launch_status();
 }
@@ -317,8 +319,10 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   const int per_out = 4 * 256 * (256 / 4 + 1);   // 4 lanes per item; items = rows x (4-column groups + the bias)
   {
     ProfScope ps(K_MLP_WGRAD_REDUCE, s);
-    mlp_wgrad_reduce_kernel<P><<<dim3((per_out + 255) / 256, (unsigned)w.n_outs), dim3(256), 0, s>>>(w, grad, accumulate);
-    if (rc) mlp_wgrad_reduce_kernel<P><<<dim3((per_out + 255) / 256, (unsigned)pp.red.n_outs), dim3(256), 0, s>>>(pp.red, grad, accumulate);
+    ReduceArgs ra{};
+    append_reduce(ra, w);
+    if (rc) append_reduce(ra, pp.red);   // (same partial-sum buffer and G block)
+    mlp_wgrad_reduce_kernel<P><<<dim3((per_out + 255) / 256, (unsigned)ra.n_outs), dim3(256), 0, s>>>(ra, grad, accumulate);
     if (c->use_viewdirs) {
       PostArgs pa{};
       pa.params = params; pa.post = w.post; pa.grad = grad;

@@ -427,8 +427,32 @@ template <int P> __device__ __forceinline__ int slot_true_index(int kind, int x,
   return (P == kBF16) ? 8 * g + e : 2 * e + g;  // SRC_OUT (single frag): raw channel
 }
 
+// One launch reduces the outputs of every job table of a backward pass (the plain pass's and the layer-pair kernel's): each
+// output carries the fields of its job it needs.
+struct ReduceOut {
+  WgradOut o;
+  int nta, ntb, n_splits;
+  int64_t part_off, bias_part_off;
+};
+constexpr int kMaxReduceOuts = 28;
+struct ReduceArgs {
+  int n_outs;
+  ReduceOut out[kMaxReduceOuts];
+  const float* part;
+  float* post;      // G block or null
+};
+inline void append_reduce(ReduceArgs& r, const WgradArgs& w) {
+  for (int i = 0; i < w.n_outs && r.n_outs < kMaxReduceOuts; ++i) {
+    ReduceOut& R = r.out[r.n_outs++];
+    const WgradJob& J = w.job[w.out[i].job];
+    R.o = w.out[i];
+    R.nta = J.nta; R.ntb = J.ntb; R.n_splits = J.n_splits; R.part_off = J.part_off; R.bias_part_off = J.bias_part_off;
+  }
+  r.part = w.part; r.post = w.post;
+}
+
 template <int P>
-__global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, int accumulate) {
+__global__ void mlp_wgrad_reduce_kernel(ReduceArgs a, float* __restrict__ grad, int accumulate) {
   // Every parameter element is produced by exactly one (output, row, column): without `accumulate` the result is
   // stored, not added, and the gradient buffer needs no clearing first
   // (tests/test_gpu_kernels.py: test_mlp_backward_overwrites_every_element).
@@ -436,8 +460,8 @@ __global__ void mlp_wgrad_reduce_kernel(WgradArgs a, float* __restrict__ grad, i
   // extra item per row is the bias); the wave's four groups each sum every fourth split plane and are combined with two
   // cross-lane adds, which quadruples the loads in flight of this short, latency-bound kernel.  The summation order is
   // fixed: results are deterministic.
-  const WgradOut& O = a.out[blockIdx.y];
-  const WgradJob& J = a.job[O.job];
+  const ReduceOut& J = a.out[blockIdx.y];
+  const WgradOut& O = J.o;
   const int NA = J.nta * 32, NB = J.ntb * 32, NQ = O.cols / 4;
   const int lane = threadIdx.x & 63, r = lane >> 4;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;

@@ -63,6 +63,9 @@ struct PairArgs {
 };
 
 constexpr int kPairWaves = 4;
+#ifndef SNR_PAIR_PREFETCH
+#define SNR_PAIR_PREFETCH 0   // the next body's leading reads are issued by this body's tail as compiler-visible loads
+#endif
 #ifndef SNR_PAIR_ABLATE
 #define SNR_PAIR_ABLATE 0   // timing experiments (results are garbage): 1 no DMA in the tile loop, 2 no LDS waits, 4 no barrier,
 #endif                      // 8 no finishing VALU work (relu / flags), 16 no rebuild MFMAs, 32 no accumulating MFMAs, 64 no operand reads, 128 no row sums
@@ -85,7 +88,7 @@ constexpr int kPairWaves = 4;
 // Every LDS read is issued LA steps ahead of its MFMAs, across the loop's back edge for the head.  Completion is counted:
 // LDS operations retire in order, so the wait in front of an even step (it covers the odd step behind it too) allows
 // exactly the reads issued since (PairProg::young_pair).
-enum { EV_ISSUE = 0, EV_FLAGS, EV_STEP_A, EV_STEP_B, EV_CVT, EV_SYNC, EV_DMA, EV_SUM, EV_SUMA, EV_ADVANCE };
+enum { EV_ISSUE = 0, EV_FLAGS, EV_STEP_A, EV_STEP_B, EV_CVT, EV_SYNC, EV_DMA, EV_SUM, EV_SUMA, EV_ADVANCE, EV_PREFETCH };
 template <int TYPE, int KX> struct PairCfg {
   static constexpr bool PB = TYPE == 1;
   static constexpr int KR = PB ? 16 : KX;        // fragments of the rebuild's contraction
@@ -149,9 +152,13 @@ template <int TYPE, int KX> struct PairProg {
     // the first conversion items (they need no LDS data: the wait for the reads falls behind them).  No asm read is ever in
     // flight across the loop's back edge or at its exit: for the compiler such a read is complete when issued, and a copy it
     // places at a loop boundary (or a reuse of the register behind the loop) would meet the old register content.
-    const int n_top = C::PB ? 4 : 6;                 // conversion micro-items at the top
-    if (C::PB) { push(EV_FLAGS, 2, 0); push(EV_FLAGS, 3, 0); }
-    for (int i = 0; i < NS; ++i) if (ip[i] < 0) push(EV_ISSUE, i, 0);
+    // (SNR_PAIR_PREFETCH: those reads are issued by the previous body's tail instead, as loads the compiler knows — it waits
+    //  for them itself, at the loop head, and never touches a register they are due in)
+    const int n_top = SNR_PAIR_PREFETCH ? 0 : (C::PB ? 4 : 6);   // conversion micro-items at the top
+    if (!SNR_PAIR_PREFETCH) {
+      if (C::PB) { push(EV_FLAGS, 2, 0); push(EV_FLAGS, 3, 0); }
+      for (int i = 0; i < NS; ++i) if (ip[i] < 0) push(EV_ISSUE, i, 0);
+    }
     for (int u = 0; u < n_top; ++u) push(EV_CVT, 16 * 1 + u, 0);
     for (int p = 0; p < NS; ++p) {
       push(EV_STEP_A, p, 0);
@@ -161,6 +168,7 @@ template <int TYPE, int KX> struct PairProg {
           // (... second half — in front of this gap's reads: with WIN = LA + 1 the reads of step p + LA reuse the registers of step p - 1)
           if (p > 0 && order[p - 1] < 0 && !C::PB) push(EV_SUMA, 2 * (p - 1) + 1, 0);
           for (int i = 0; i < NS; ++i) if (ip[i] == p) push(EV_ISSUE, i, 0);
+          if (SNR_PAIR_PREFETCH) for (int i = 0; i < NS; ++i) if (ip[i] < 0 && ip[i] + NS == p) push(EV_PREFETCH, i, 1);
         } else {
           push(EV_STEP_B, p, 0);
           if (p == C::SYNC_STEP) push(EV_SYNC, 0, 0);
@@ -175,7 +183,11 @@ template <int TYPE, int KX> struct PairProg {
         if (g == G - 1 && order[NS - 1] < 0 && !C::PB) push(EV_SUMA, 2 * (NS - 1) + 1, 0);
         for (int u = 0; u < 16; ++u) {
           if (u >= n_top && (u - n_top) * hi_gaps / (16 - n_top) == g && g < hi_gaps) push(EV_CVT, 16 * 1 + u, 0);
-          if (lo_gap0 + u * lo_gaps / 16 == g) push(EV_CVT, 16 * 0 + u, 0);
+          if (lo_gap0 + u * lo_gaps / 16 == g) {
+            push(EV_CVT, 16 * 0 + u, 0);
+            if (SNR_PAIR_PREFETCH && C::PB && u == 7) push(EV_PREFETCH, NS + 2, 1);    // flag registers of quad 0 / 1 used up:
+            if (SNR_PAIR_PREFETCH && C::PB && u == 15) push(EV_PREFETCH, NS + 3, 1);   // the next tile's k-step-1 flag words
+          }
         }
       }
     }
@@ -192,8 +204,14 @@ template <int TYPE, int KX> struct PairProg {
   }
   constexpr int find(int k, int a) const { for (int j = 0; j < n; ++j) if (kind[j] == k && arg[j] == a) return j; return -1; }
   // e: the EV_STEP_A event of an even step; its wait also covers step + 1 (one s_waitcnt per two steps), whose reads are the younger
-  constexpr int young_pair(int e) const { return between(find(EV_ISSUE, arg[e] + 1), e); }
-  constexpr int young_flags(int t, int e) const { return between(find(EV_FLAGS, t), e); }  // e: the event that uses them
+  constexpr int young_pair(int e) const {
+    const int is = find(EV_ISSUE, arg[e] + 1);
+    return is < 0 ? 15 : between(is, e);   // (prefetched by the previous body as a compiler-visible load: the compiler waits)
+  }
+  constexpr int young_flags(int t, int e) const {   // e: the event that uses them
+    const int is = find(EV_FLAGS, t);
+    return is < 0 ? 15 : between(is, e);
+  }
   constexpr int first_rstep() const { for (int i = 0; i < NS; ++i) if (order[i] >= 0) return i; return -1; }
   constexpr bool valid() const {
     if (NS % C::WIN || C::WIN <= LA || NS % 2) return false;
@@ -494,6 +512,22 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
         constexpr int t = arg / 2, quad = arg % 2;
 #pragma unroll
         for (int c = 0; c < 2; ++c) pair_read16u<64 * t + 32 * quad>(fw[c][quad], (nxt ? sN : sA) + fl_addr[c]);
+      } else if constexpr (kind == EV_PREFETCH) {
+        // reads for the NEXT body's head, as loads the compiler tracks (it inserts the wait at their first use and never
+        // copies or reuses their registers early, which it is free to do with an asm read's)
+        typedef short s16x4_t __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4;
+        typedef __attribute__((address_space(3))) u32x4* lds_u32x4;
+        if constexpr (arg < NS) {
+          constexpr int e = ~PG.order[arg], t = e / NM, m = e % NM;
+          tl[arg % WIN] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(aTn + m * 2048 + t * 512)));
+          th[arg % WIN] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(aTn + m * 2048 + t * 512 + 256)));
+        } else {
+          constexpr int quad = arg - NS - 2;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) fw[c][quad] = *(lds_u32x4)(sN + fl_addr[c] + 64 + 32 * quad);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       } else if constexpr (kind == EV_STEP_A || kind == EV_STEP_B) {
         constexpr int o = PG.order[arg];
         constexpr int c = kind == EV_STEP_B ? 1 : 0;   // the column block of this MFMA
@@ -519,7 +553,14 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
             // (tools/check_lds_asm.py verifies on the listing that no VALU instruction writes an MFMA operand in the two
             //  wait states in front of it: the compiler is free to assemble this tuple with moves)
             const Frag fa = Frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if constexpr (!(SNR_PAIR_ABLATE & 32) || m == 0) pair_mfma_acc(acc[c][m], fa, P[c][t]);
+            // kind A multiplies the other way round — P as the A operand (rows = its columns j), the transposed read as B (columns =
+            // d z slots): the tile comes out as dW_{2k+1}^T... i.e. [j][slot] with lane = slot, which makes its partial plane
+            // [slot][j] row-major like the plain pass's (the reduce kernel scatters it with coalesced stores); the register
+            // images of the two operands are the same either way
+            if constexpr (!(SNR_PAIR_ABLATE & 32) || m == 0) {
+              if constexpr (PB) pair_mfma_acc(acc[c][m], fa, P[c][t]);
+              else pair_mfma_acc(acc[c][m], __builtin_bit_cast(Frag, P[c][t]), __builtin_bit_cast(u32x4, fa));
+            }
           }
         }
         // nothing moves across an MFMA: what the schedule puts between two of them stays in that shadow (left alone, the
@@ -585,9 +626,11 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
   // trailing DMA loads; 12+ wait states from the last MFMA to the accumulator reads
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-  // ---- partial sums: plane [256 columns][32 NM rows], bf16; lane (column, half gg) holds rows 8 k + 4 gg + 0..3 of every
-  // row tile in registers 4 k .. 4 k + 3: one 8-byte store each ----
-  constexpr int NB = 32 * NM;
+  // ---- partial sums, bf16, one 8-byte store per four registers ----
+  //   kind B: plane [256 neurons n of layer 2k][32 NM X slots]: lane (n, half gg) holds slots 8 k + 4 gg + 0..3 of every row tile
+  //   kind A: plane [256 d z_{2k+1} slots][256 columns j of h_2k]: lane (slot 32 m + lane & 31, half gg) holds columns
+  //           64 wave + 32 c + 8 k + 4 gg + 0..3
+  constexpr int NB = PB ? 32 * NM : 256;
   __bf16* plane = (__bf16*)(a.part + H.part_off + (int64_t)split * 256 * NB);
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -597,7 +640,8 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const bf16x4 h = {(__bf16)acc[c][m][4 * k], (__bf16)acc[c][m][4 * k + 1], (__bf16)acc[c][m][4 * k + 2], (__bf16)acc[c][m][4 * k + 3]};
-        *(bf16x4*)(plane + col * NB + 32 * m + 8 * k + 4 * gg) = h;
+        if constexpr (PB) *(bf16x4*)(plane + col * NB + 32 * m + 8 * k + 4 * gg) = h;
+        else *(bf16x4*)(plane + (int64_t)(32 * m + (lane & 31)) * NB + 64 * wave + 32 * c + 8 * k + 4 * gg) = h;
       }
   }
   float* bp = a.part + H.bias_part_off + (int64_t)split * 256;
@@ -724,7 +768,7 @@ inline PairPlan make_pair_plan(const snr_mlp_config* c, int64_t n_samples, int64
     J.a.bias_part_off = po; po += s * 256;
     J.b.part_off = po; po += s * 256 * 32 * NMb;
     J.b.bias_part_off = po; po += s * 256;
-    // reduce table: kind A planes [column j of h_{la} (true order)][row = d z_{lb} slot] -> dW_{lb}[true(row)][j]
+    // reduce table: kind A planes [row = d z_{lb} slot][column j of h_{la} (true order)] -> dW_{lb}[true(row)][j], row sums -> db_{lb}
     auto rjob = [&](int nta, int ntb, int64_t part_off, int64_t bias_part_off) {
       WgradJob& Q = R.job[nj];
       Q.nta = nta; Q.ntb = ntb; Q.n_splits = (int)s; Q.split_begin = 0; Q.part_off = part_off; Q.bias_part_off = bias_part_off;
@@ -739,9 +783,7 @@ inline PairPlan make_pair_plan(const snr_mlp_config* c, int64_t n_samples, int64
     };
     const int ld_b = lb == kSkip + 1 ? kW + ip : kW, co_b = lb == kSkip + 1 ? ip : 0;
     int j = rjob(8, 8, J.a.part_off, J.a.bias_part_off);
-    rout(j, kW, SRC_NAT, kW, SRC_H, 0, L.w_pts[lb], ld_b, co_b, kW, kW, -1, 1);
-    j = rjob(8, 0, J.a.part_off, J.a.bias_part_off);   // its row sums of d z_{lb}: the bias gradient, indexed by the slot order
-    rout(j, 8 * 2 * SPF, SRC_H, 0, SRC_H, 0, 0, 0, 0, kW, 0, L.b_pts[lb], 0);
+    rout(j, kW, SRC_H, kW, SRC_NAT, 0, L.w_pts[lb], ld_b, co_b, kW, kW, L.b_pts[lb], 0);
     // kind B planes [neuron n of layer la (true order)][row = X slot] -> dW_{la}[n][true(row)], column sums -> db_{la}
     j = rjob(8, NMb, J.b.part_off, J.b.bias_part_off);
     if (k == 0) rout(j, kW, SRC_NAT, 32 * NMb, SRC_ENC_PTS, L_pts, L.w_pts[la], ip, 0, kW, ip, L.b_pts[la], 0);
