@@ -30,6 +30,10 @@ sys.path.insert(0, ROOT)
 MAC_FWD = 63 * 256 + 4 * 256 * 256 + 319 * 256 + 2 * 256 * 256 + 256 * 256 + 256 + 283 * 128 + 128 * 3
 MAC_WGRAD = MAC_FWD
 MAC_DGRAD = MAC_FWD - (63 * 256 + 63 * 256 + 27 * 128)
+# bf16 mode splits the weight-gradient pass: the layer-pair kernel (`mlp_wgrad_pair`) owns the eight trunk
+# layers except the skip layer's 63 encoding columns; the plain split-K kernel (`mlp_wgrad`) keeps those and the head
+MAC_WGRAD_PAIR = 63 * 256 + 7 * 256 * 256
+MAC_WGRAD_REST = MAC_WGRAD - MAC_WGRAD_PAIR
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
 
@@ -103,6 +107,7 @@ def main():
     ap.add_argument("--n-coarse", type=int, default=64)
     ap.add_argument("--n-fine", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=5, help="back-to-back timed blocks of --steps steps; the median block is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frame", action="store_true")
     ap.add_argument("--no-hashgrid", action="store_true", help="skip the extra measurements (BASELINE config 5 hash-grid networks, config 3 iteration)")
@@ -161,18 +166,37 @@ def main():
             rays, target = batches[(first + i) % n_batches]
             trainer.step(H, W, focal, rays, target)
 
+    # W untimed warm-up steps, then R back-to-back blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both
+    # sides and reduced with MAX over the ranks; the MEDIAN block is the reported step time (one 20-step block is a 20 ms
+    # sample: bimodal at +-2 % and invisible to a 5 s SMI sampler — VERDICT r02), all blocks are listed in `block_ms`
     run_steps(ns.warmup, 0)
-    sync_all()
-    t0 = time.perf_counter()
-    run_steps(ns.steps, ns.warmup)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    block_s = []
+    trainer.comm_reset()
+    for b in range(max(1, ns.blocks)):
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps(ns.steps, ns.warmup + b * ns.steps)
+        sync_all()
+        e = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([e], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        block_s.append(e)
+    elapsed = float(np.median(block_s))
+    rays_per_s = world * ns.n_rand * ns.steps / elapsed
+    comm_ms = trainer.comm_ms_per_step()          # exposed part of the gradient all-reduce (None on one GPU)
+    dist_info = None
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    rays_per_s = world * ns.n_rand * ns.steps / elapsed
+        mine = torch.tensor([torch.cuda.current_device()], device=device, dtype=torch.int64)
+        devs = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(devs, mine)
+        dist_info = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                     "local_device_of_rank": [int(d.item()) for d in devs],
+                     "allreduce_ms_per_step_exposed": comm_ms,
+                     "gradient_bytes_per_step": int(sum(n.flat.numel() for n in trainer.nets) * 4)}
 
     # ---- per-kernel timing with HIP events on the launch stream: the same K steps again, profiled ----
     graph_route = bool(getattr(trainer, "_graph", None))
@@ -202,6 +226,31 @@ def main():
             torch.cuda.synchronize()
             ms_frame = (time.perf_counter() - tf) / nf * 1e3
 
+    # The reference's own arithmetic is fp32: the same workload in the exact-fp32 MFMA mode, beside the headline
+    fp32_mode = None
+    if not ns.no_hashgrid and rank == 0 and world == 1 and ns.precision == "bf16":
+        fargs = make_args(ns)
+        fargs.precision = "fp32"
+        with contextlib.redirect_stdout(io.StringIO()):
+            fkw, *_ = S.create_nerf(fargs, device=device)
+        fkw.update(near=near, far=far)
+        ftr = RenderTrainer(fkw, lrate=5e-4, lrate_decay=250)
+        nst = max(4, ns.steps // 5)
+        for i in range(3):
+            ftr.step(H, W, focal, *batches[i % n_batches])
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for i in range(nst):
+            ftr.step(H, W, focal, *batches[(3 + i) % n_batches])
+        torch.cuda.synchronize()
+        tf0 = (time.perf_counter() - tf0) / nst
+        evals = ns.n_rand * (ns.n_coarse + (ns.n_coarse + ns.n_fine if ns.n_fine else 0))
+        fl = 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) * evals
+        fp32_mode = {"workload": "same step, --precision fp32 (v_mfma_f32_32x32x2_f32: the reference's arithmetic)",
+                     "rays_per_s": ns.n_rand / tf0, "ms_per_step": tf0 * 1e3, "steps": nst,
+                     "step_tflops_algorithmic": fl / tf0 / 1e12, "peak": PEAK_TFLOPS["fp32"], "frac": fl / tf0 / 1e12 / PEAK_TFLOPS["fp32"]}
+        del ftr, fkw
+
     # BASELINE config 5 (the reference's default networks: hash grid + two small MLPs, create_nerf_tcnn) on the same ray
     # batches — reported beside the headline workload, never as `value` (its parity is unpinned)
     hashgrid = None
@@ -221,9 +270,35 @@ def main():
             htr.step(H, W, focal, *batches[(ns.warmup + i) % n_batches])
         torch.cuda.synchronize()
         th = (time.perf_counter() - th) / ns.steps
+        S._lib.prof_enable(True)
+        S._lib.prof_read()
+        for i in range(ns.steps):
+            htr.step(H, W, focal, *batches[i % n_batches])
+        torch.cuda.synchronize()
+        hprof = S._lib.prof_read()
+        S._lib.prof_enable(False)
+        hk = {k: v[0] / ns.steps for k, v in hprof.items()}
+        hg_samples = ns.n_rand * (ns.n_coarse + (ns.n_coarse + ns.n_fine if ns.n_fine else 0))
         hashgrid = {"workload": "same rays and sample counts, NeRF_TCNN coarse + fine (16-level 2^19 hash grid, SH4, 64-wide "
                                 "MLPs), render+mse(rgb)+mse(rgb0)+backward+dense Adam", "rays_per_s": ns.n_rand / th,
-                    "ms_per_step": th * 1e3, "parity": "unpinned"}
+                    "ms_per_step": th * 1e3, "parity": "unpinned",
+                    "dtype_note": "bf16 MFMA for the two small MLPs where tiny-cuda-nn computes in fp16 (unpinnable: the dependency is absent)",
+                    "kernels_ms_per_step": hk}
+        if hk.get("hg_bwd") and hk.get("hg_fwd"):
+            # What bounds the two kernels is measured, not MFMA (20 KFLOP per sample): the table scatter runs against the
+            # atomic unit, the encoding against the gather path (tests/probes/atomic_rate.hip, profiles/r02_atomic_rate.txt:
+            # 16 lanes on one 64-byte line sustain 325 G lane-atomics/s, two lanes per cell 42 G/s, random 8-byte gathers
+            # from the 56 MB table 59 G cells/s).  Algorithmic units: 16 levels x 8 corners x 2 features per sample.
+            la = 16 * 8 * 2 * hg_samples
+            hashgrid["roofline"] = {
+                "kernel": "hg_bwd", "bound": "atomic unit (requests, not bytes)", "achieved": la / (hk["hg_bwd"] * 1e-3) / 1e9,
+                "peak": 325.0, "unit": "G lane-atomics/s", "frac": la / (hk["hg_bwd"] * 1e-3) / 1e9 / 325.0,
+                "note": "lane-atomics BEFORE the kernel's merging of lanes that share a cell; the unit itself retires 21 G "
+                        "(instruction, line) requests/s, so the kernel issues at most 21e9 x its launch time of them",
+                "requests_per_launch_upper_bound": 21e9 * hk["hg_bwd"] * 1e-3 / 2,
+                "forward_gather": {"achieved": 16 * 8 * hg_samples / (hk["hg_fwd"] * 1e-3) / 1e9, "peak_random": 59.0,
+                                   "unit": "G cells/s (8-byte gathers)",
+                                   "note": "above the random-gather rate because neighbouring samples of a ray share cells at the coarse levels"}}
         if not ns.no_frame:
             c2w_h = torch.eye(4)[:3, :4].to(device)
             with torch.no_grad():
@@ -266,7 +341,10 @@ def main():
         return
     n_c, n_f = ns.n_rand * ns.n_coarse, ns.n_rand * (ns.n_coarse + ns.n_fine)
     evals_per_step = n_c + (n_f if ns.n_fine else 0)
-    flops = {"mlp_fwd": 2 * MAC_FWD, "mlp_dgrad": 2 * MAC_DGRAD, "mlp_wgrad": 2 * MAC_WGRAD}
+    recompute = "mlp_wgrad_pair" in prof
+    flops = {"mlp_fwd": 2 * MAC_FWD, "mlp_dgrad": 2 * MAC_DGRAD, "mlp_wgrad": 2 * (MAC_WGRAD_REST if recompute else MAC_WGRAD)}
+    if recompute:
+        flops["mlp_wgrad_pair"] = 2 * MAC_WGRAD_PAIR
     kernels = {}
     for k, (ms, cnt) in prof.items():
         kernels[k] = {"ms_per_step": ms / ns.steps, "launches_per_step": cnt / ns.steps}
@@ -310,10 +388,24 @@ def main():
         stream_bytes = {"mlp_wgrad": 2 * wg_elems,                               # every saved section of a job read once
                         "mlp_fwd": 2 * (64 + 8 * 256 + 32 + 128) + 9 * 32,        # encodings, h0..h7, h9, flags
                         "mlp_dgrad": 2 * (16 + 8 * 256 + 128) + 9 * 32}           # d out, d z0..7, d z9 (+ flags read)
+        if recompute:
+            # odd layers only (mlp_wgrad_pair.h): forward h1,h3,h5,h7; dgrad d z1,3,5,7; the pair kernel fetches each pair's two
+            # tensors + 32 B of flags ONCE from HBM (its two kinds of workgroup share the fetch through L2)
+            stream_bytes = {"mlp_fwd": 2 * (64 + 4 * 256 + 32 + 128) + 9 * 32,
+                            "mlp_dgrad": 2 * (16 + 4 * 256 + 128) + 9 * 32,
+                            "mlp_wgrad_pair": 2 * (64 + 256) + 32 + 3 * (2 * 512 + 32),
+                            "mlp_wgrad": 2 * ((256 + 64) + (128 + 16 + 256 + 32) + (16 + 128))}
         for k, b in stream_bytes.items():
             if k in kernels:
                 gbps = b * evals_per_step / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
                 kernels[k]["stream_GBps"] = gbps
+        if recompute and dom == "mlp_wgrad_pair":
+            # the kernel executes about twice its algorithmic MFMAs (it rebuilds h_2k and d z_2k): matrix-pipe time it cannot avoid
+            mf = (320 + 512 + 512 + 512) * 32768 / 32          # MFMA FLOPs per sample: 1856 MFMAs per 32-sample tile (mlp_wgrad_pair.h)
+            roofline["mfma_executed"] = {"flops_per_launch": mf * evals_per_step / launches,
+                                         "achieved": mf * evals_per_step / (kernels[dom]["ms_per_step"] * 1e-3) / 1e12,
+                                         "frac": mf * evals_per_step / (kernels[dom]["ms_per_step"] * 1e-3) / 1e12 / peak,
+                                         "note": "incl. the recomputed layers; `achieved` above counts algorithmic FLOPs only"}
         roofline["stream"] = {"bytes_per_launch": stream_bytes[dom] * evals_per_step / launches,
                               "achieved": kernels[dom]["stream_GBps"], "peak": 8000.0, "unit": "GB/s",
                               "frac": kernels[dom]["stream_GBps"] / 8000.0}
@@ -329,13 +421,18 @@ def main():
         "ms_per_frame_378x504": ms_frame,
         "step_tflops_algorithmic": step_flops / (elapsed / ns.steps) / 1e12,
         "hbm_bytes_per_step": hbm_step,
+        "blocks": len(block_s), "block_ms": [round(b * 1e3, 4) for b in block_s],
         "roofline": roofline,
         "kernels": kernels,
         "ms_per_step_profiled": prof_elapsed / ns.steps * 1e3,
         "step_route": "captured HIP graph replay (SNR_STEP_GRAPH=1)" if graph_route else "two fused library calls + Adam per step",
     }
+    if dist_info is not None:
+        out["distributed"] = dist_info
     if hashgrid is not None:
         out["also_measured"] = {"hashgrid_config5": hashgrid}
+    if fp32_mode is not None:
+        out.setdefault("also_measured", {})["fp32_mode"] = fp32_mode
     if spin is not None:
         out.setdefault("also_measured", {})["spin_iteration_config3"] = spin
     if not ns.no_cpu_baseline and world == 1:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SNR_ABI_VERSION 1
+#define SNR_ABI_VERSION 2   /* 2: snr_mlp_backward / snr_pack_rays argument lists, snr_net / snr_step_state (round 2) */
 
 #define SNR_OK 0
 #define SNR_ERR_NULL (-1)         /* a required pointer is NULL */

@@ -109,6 +109,9 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2   # include/spinnerf_hip.h: SNR_ABI_VERSION (bumped whenever a prototype or a shared struct changes)
+
+
 def load():
     """Load the shared library (once).  Fails loudly: the product path has no fallback."""
     global _lib
@@ -125,7 +128,7 @@ def load():
         except AttributeError as e:
             raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
-    if lib.snr_abi_version() != 1:
+    if lib.snr_abi_version() != ABI_VERSION:
         raise HipLibraryError("ABI version mismatch")
     _lib = lib
     return lib

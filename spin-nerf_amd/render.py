@@ -308,22 +308,44 @@ def _load_per_layer_adam(optimizer, osd, nets):
             g['lr'] = osd['param_groups'][0]['lr']
     if not st:
         return
-    if len(st) != n_params:
-        raise RuntimeError(f"optimizer_state_dict holds Adam state for {len(st)} parameter tensors, these networks "
-                           f"register {n_params} (e.g. --alpha_model_path checkpoints list the frozen density network "
-                           "as well): cannot resume the optimizer")
-    idx = 0
-    for n in nets:
-        m, v = torch.zeros_like(n.flat.data), torch.zeros_like(n.flat.data)
+    moments = [(torch.zeros_like(n.flat.data), torch.zeros_like(n.flat.data)) for n in nets]
+    steps = scatter_per_layer_adam(st, nets, moments)
+    for n, (m, v), stp in zip(nets, moments, steps):
+        optimizer.state[n.flat] = {'step': torch.tensor(float(stp)), 'exp_avg': m, 'exp_avg_sq': v}
+
+
+def scatter_per_layer_adam(st, nets, moments):
+    """Per-layer torch.optim.Adam state `st` (index -> {step, exp_avg, exp_avg_sq}, coarse network first) into the flat
+    moment buffers `moments` = [(m, v)] of `nets`; returns the step count of each network.  A layer without an entry is
+    accepted where the reference gives that layer no gradient — views_linears.* of a network built without
+    use_viewdirs is registered but never used (helpers:86-90, 118-120), so torch.optim.Adam creates no state for it and
+    the indices of a genuine reference checkpoint have holes there: its moments stay zero.  Anything else that does not
+    correspond raises (a resumed run must not silently restart moments, bias correction and learning-rate decay)."""
+    n_params = sum(len(n.param_views()) for n in nets)
+    unknown = [k for k in st if not (isinstance(k, int) and 0 <= k < n_params)]
+    if unknown:
+        raise RuntimeError(f"optimizer_state_dict holds Adam state for parameter indices {sorted(map(str, unknown))[:4]}..., these "
+                           f"networks register {n_params} parameter tensors (e.g. --alpha_model_path checkpoints list the "
+                           "frozen density network as well): cannot resume the optimizer")
+    idx, out = 0, []
+    for n, (m, v) in zip(nets, moments):
+        m.zero_(); v.zero_()
         steps = set()
-        for mv, vv in zip(n.param_views(m).values(), n.param_views(v).values()):
-            e = st[idx]
-            mv.copy_(e['exp_avg'].reshape(mv.shape)); vv.copy_(e['exp_avg_sq'].reshape(vv.shape))
-            steps.add(float(e['step']))
+        for (name, mv), vv in zip(n.param_views(m).items(), n.param_views(v).values()):
+            e = st.get(idx)
+            if e is None:
+                if not (name.startswith("views_linears") and not getattr(n, "use_viewdirs", True)):
+                    raise RuntimeError(f"optimizer_state_dict has no Adam state for parameter {idx} ({name}): cannot resume the optimizer")
+            else:
+                if e['exp_avg'].numel() != mv.numel():
+                    raise RuntimeError(f"Adam state of parameter {idx} ({name}) has {e['exp_avg'].numel()} elements, the layer {mv.numel()}")
+                mv.copy_(e['exp_avg'].reshape(mv.shape)); vv.copy_(e['exp_avg_sq'].reshape(vv.shape))
+                steps.add(float(e['step']))
             idx += 1
-        if len(steps) != 1:
+        if len(steps) > 1:
             raise RuntimeError(f"layers of one network disagree on the Adam step count: {sorted(steps)}")
-        optimizer.state[n.flat] = {'step': torch.tensor(steps.pop()), 'exp_avg': m, 'exp_avg_sq': v}
+        out.append(steps.pop() if steps else 0.0)
+    return out
 
 
 def create_nerf(args, device=None):

@@ -288,13 +288,25 @@ class RenderTrainer:
         they are overwritten by the next step."""
         # (the graph holds raw pointers: a parameter or moment buffer that moved — .to(), a re-created network — means a
         #  new capture, not a replay into freed memory)
+        # ... and so does everything the capture bakes in: the render configuration, the rate schedule, the networks' precision
+        kw = self.kw
+        baked = tuple((k, float(kw[k]) if isinstance(kw.get(k), (int, float)) and not isinstance(kw.get(k), bool) else kw.get(k))
+                      for k in ('N_samples', 'N_importance', 'perturb', 'raw_noise_std', 'white_bkgd', 'lindisp', 'near', 'far', 'ndc',
+                                'use_viewdirs') if not isinstance(kw.get(k), torch.Tensor))
         key = (H, W, float(focal), tuple(batch_rays.shape), str(batch_rays.device),
-               tuple(n.flat.data_ptr() for n in self.nets), tuple(m.data_ptr() for m in self.m + self.v))
+               tuple(n.flat.data_ptr() for n in self.nets), tuple(m.data_ptr() for m in self.m + self.v),
+               baked, float(self.lrate), float(self.lrate_decay),
+               tuple(n.cfg.key() if hasattr(getattr(n, "cfg", None), "key") else None for n in self.nets))
         if self._graph is None or self._graph["key"] != key:
             if self._graph_warm != key:
                 self._graph_warm = key
                 return self._step_direct(H, W, focal, batch_rays, target_s, None)
-            self._capture(H, W, focal, batch_rays, target_s, key)
+            try:
+                self._capture(H, W, focal, batch_rays, target_s, key)
+            except Exception:
+                # a failed capture must not be retried on every step: forget the warm-up state and take the eager route
+                self._graph, self._graph_warm, self._graph_on = None, None, False
+                return self._step_direct(H, W, focal, batch_rays, target_s, None)
         G = self._graph
         if G["expect"] != (self._draws, self.opt_step, self.global_step):   # eager steps / a checkpoint moved the counters
             self._upload_state(G)
@@ -474,21 +486,14 @@ class RenderTrainer:
         self.global_step = int(ckpt['global_step'])
         osd = ckpt['optimizer_state_dict']
         st = osd['state']
-        n_params = sum(len(n.param_views(m)) for n, m in zip(self.nets, self.m))
-        if st and len(st) != n_params:
-            raise RuntimeError(f"checkpoint holds Adam state for {len(st)} parameters, these networks have {n_params}")
-        idx, steps = 0, set()
-        for n, m, v in zip(self.nets, self.m, self.v):
+        from .render import scatter_per_layer_adam
+        for m, v in zip(self.m, self.v):
             m.zero_(); v.zero_()
-            for mv, vv in zip(n.param_views(m).values(), n.param_views(v).values()):
-                if idx in st:
-                    mv.copy_(st[idx]['exp_avg'].reshape(mv.shape))
-                    vv.copy_(st[idx]['exp_avg_sq'].reshape(vv.shape))
-                    steps.add(int(st[idx]['step']))
-                idx += 1
+        steps = set(scatter_per_layer_adam(st, self.nets, list(zip(self.m, self.v)))) if st else set()
+        steps.discard(0.0) if len(steps) > 1 else None      # (a network all of whose layers are idle carries no step count)
         if len(steps) > 1:
             raise RuntimeError(f"checkpoint parameters disagree on the Adam step count: {sorted(steps)}")
-        self.opt_step = steps.pop() if steps else 0
+        self.opt_step = int(steps.pop()) if steps else 0
         self._lr = float(osd['param_groups'][0]['lr']) if osd.get('param_groups') else self.lrate
         for n in self.nets:
             n.mark_weights_changed()
@@ -496,17 +501,41 @@ class RenderTrainer:
     def load_checkpoint(self, path, map_location=None):
         self.load_state_dict(torch.load(path, map_location=map_location, weights_only=False))
 
+    # ---- exposed communication time (bench.py's `distributed.allreduce_ms_per_step_exposed`) ----
+    def comm_reset(self):
+        self._comm_events, self._comm_steps = [], 0
+
+    def comm_ms_per_step(self):
+        """Stream time the optimizer step spent waiting for the gradient all-reduce (events around the waits), per step
+        since comm_reset(); None on one GPU."""
+        if self.world_size <= 1 or not getattr(self, "_comm_steps", 0):
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._comm_events) / self._comm_steps
+
     def apply_gradients(self):
         if self.world_size > 1:
             import torch.distributed as dist
+            idle = []                            # networks without a gradient: every rank agrees on which (same code path)
             for i, n in enumerate(self.nets):   # anything the hooks did not see (gradients set by hand)
                 if i not in self._works:
-                    if n.flat.grad is None:     # a network that took no part in this step still joins the collective
+                    if n.flat.grad is None:     # a network that took no part in this step still joins the collective ...
                         n.flat.grad = torch.zeros_like(n.flat.data)
+                        idle.append(n)
                     self._start_all_reduce(i, n.flat)
+            timed = hasattr(self, "_comm_events") and self.nets[0].flat.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             for w in self._works.values():
                 w.wait()
+            if timed:
+                e1.record()
+                self._comm_events.append((e0, e1))
+                self._comm_steps += 1
             self._works.clear()
+            for n in idle:                       # ... but takes no Adam step, exactly like the single-process path
+                n.flat.grad = None
         self.opt_step += 1
         lr = self._lr
         for n, m, v in zip(self.nets, self.m, self.v):

@@ -134,3 +134,50 @@ def test_nerf_rgb_draws_and_registers_what_the_reference_does():
     assert float(v["alpha_linear.weight"].abs().max()) == 0.0 and float(v["alpha_linear.bias"].abs().max()) == 0.0
     assert not any(k.startswith("alpha_linear") for k in a.param_views()) and len(a.param_views()) == 22
     assert len(S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True).param_views()) == 24
+
+
+def test_resume_from_a_per_layer_adam_without_state_for_the_unused_views_layer(monkeypatch):
+    """with use_viewdirs=False the reference still registers views_linears.0 (helpers:86-90) but never gives it
+    a gradient, so a genuine torch.optim.Adam state has no entries for those two tensors per network — its indices have
+    holes.  Such a checkpoint resumes (zero moments for the idle layer); a hole anywhere else still raises."""
+    import pytest
+    import spin_nerf_amd as S
+    train = importlib.import_module("spin-nerf_amd.train")
+    monkeypatch.setattr(train.ops, "adam_step_", _cpu_adam)
+    torch.manual_seed(0)
+    nets = [S.NeRF(input_ch=63, input_ch_views=0, output_ch=5, use_viewdirs=False) for _ in range(2)]
+    # the reference side: per-layer tensors in state-dict order, gradients for every layer but views_linears.*
+    names = [k for n in nets for k in n.named_views()]
+    params = [torch.nn.Parameter(v.clone()) for n in nets for v in n.named_views().values()]
+    opt = torch.optim.Adam(params=params, lr=1e-3, betas=(0.9, 0.999))
+    g = torch.Generator().manual_seed(3)
+    for _ in range(2):
+        for k, p in zip(names, params):
+            p.grad = None if k.startswith("views_linears") else torch.randn(p.shape, generator=g) * 1e-2
+        opt.step()
+    osd = opt.state_dict()
+    assert len(osd["state"]) == len(params) - 4 and 16 not in osd["state"]      # two idle tensors per network: holes
+    ck = {"global_step": 2, "optimizer_state_dict": osd,
+          "network_fn_state_dict": {k: p.detach() for k, p in zip(names[:len(names) // 2], params[:len(params) // 2])},
+          "network_fine_state_dict": {k: p.detach() for k, p in zip(names[len(names) // 2:], params[len(params) // 2:])}}
+    tr = train.RenderTrainer({"network_fn": nets[0], "network_fine": nets[1]}, lrate=1e-3)
+    tr.load_state_dict(ck)
+    assert tr.opt_step == 2
+    o = 0
+    for n, m, v in zip(tr.nets, tr.m, tr.v):
+        for (k, mv), vv in zip(n.param_views(m).items(), n.param_views(v).values()):
+            e = osd["state"].get(o)
+            if e is None:
+                assert k.startswith("views_linears") and float(mv.abs().max()) == 0.0 and float(vv.abs().max()) == 0.0
+            else:
+                assert torch.equal(mv, e["exp_avg"].reshape(mv.shape)) and torch.equal(vv, e["exp_avg_sq"].reshape(vv.shape))
+            o += 1
+    # a hole in a layer that does train is refused
+    bad = {"state": {k: v for k, v in osd["state"].items() if k != 3}, "param_groups": osd["param_groups"]}
+    with pytest.raises(RuntimeError, match="no Adam state for parameter 3"):
+        tr.load_state_dict(dict(ck, optimizer_state_dict=bad))
+    # ... and so is state for a tensor these networks do not have
+    st_extra = dict(osd["state"]); st_extra[len(params)] = osd["state"][0]
+    extra = {"state": st_extra, "param_groups": osd["param_groups"]}
+    with pytest.raises(RuntimeError, match="parameter indices"):
+        tr.load_state_dict(dict(ck, optimizer_state_dict=extra))

@@ -29,3 +29,9 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["config"]["global_batch_rays"] == 2048 and d["config"]["parallelism"] == "ray-dp2"
     assert d["value"] > 0 and abs(d["value"] - 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d                    # rank 0 at N=1 only
+    # the run describes itself: what the collective layer saw, and the exposed communication time
+    dd = d["distributed"]
+    assert dd["ranks_seen"] == 2 and dd["backend"] == "gloo" and dd["local_device_of_rank"] == [0, 0]
+    assert dd["gradient_bytes_per_step"] == 2 * 595844 * 4
+    assert dd["allreduce_ms_per_step_exposed"] is not None and dd["allreduce_ms_per_step_exposed"] >= 0.0
+    assert d["blocks"] == len(d["block_ms"]) >= 1 and abs(sorted(d["block_ms"])[len(d["block_ms"]) // 2] / 6 - d["ms_per_step"]) < 1e-3
