@@ -30,8 +30,17 @@ def chunked_pytest_randoms(n_rays, chunk, Nc, Nf, perturb, noise_std):
     return {k: (torch.cat(v, 0) if v[0] is not None else None) for k, v in parts.items()}
 
 
+def _bf16_bits_to_f32(a):
+    return torch.from_numpy((np.asarray(a).astype(np.uint32) << 16).view(np.float32).copy())
+
+
 def render_case_nets(g):
     vd, och, Nf = bool(g["vd"]), int(g["och"]), int(g["Nf"])
+    if any(k.startswith("wc_") for k in g):
+        # networks the REFERENCE trained (tests/golden/make_golden_trained.py): stored as bf16 bit patterns — the reference
+        # rendered the fixture with exactly these (bf16-representable) weights
+        return ({k[3:]: _bf16_bits_to_f32(v) for k, v in g.items() if k.startswith("wc_")},
+                {k[3:]: _bf16_bits_to_f32(v) for k, v in g.items() if k.startswith("wf_")})
     sd_c = O.make_wild_params(seed=11, use_viewdirs=vd, output_ch=och, input_ch_views=27 if vd else 0)
     sd_f = O.make_wild_params(seed=12, use_viewdirs=vd, output_ch=och, input_ch_views=27 if vd else 0) if Nf > 0 else None
     return sd_c, sd_f
@@ -39,7 +48,8 @@ def render_case_nets(g):
 
 RENDER_CASES = ["render_ndc_fine_vd", "render_lindisp_fine_vd", "render_lindisp_fine_vd_detach",
                 "render_ndc_coarse_vd", "render_noperturb_fine_vd_alpha", "render_ndc_fine_novd",
-                "render_c2w_fine_vd"]
+                "render_c2w_fine_vd", "render_trained_fine_vd"]
+TRAINED_CASES = ["render_trained_fine_vd"]
 R2O_CASES = ["r2o_s64", "r2o_s192_white_noise", "r2o_s192_detach", "r2o_s64_zero_sigma",
              "r2o_s64_huge_sigma", "r2o_s5"]
 PDF_CASES = ["pdf_rand", "pdf_det", "pdf_delta", "pdf_delta_det", "pdf_uniform", "pdf_zeros", "pdf_small"]
