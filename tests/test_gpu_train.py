@@ -27,14 +27,14 @@ def sphere_scene(rays_o, rays_d, white=True):
     return torch.where(hit[..., None], col, torch.ones_like(col) if white else torch.zeros_like(col))
 
 
-def train(precision, iters, n_rand=1024, seed=0, white=False, noise=1.0):
+def train(precision, iters, n_rand=1024, seed=0, white=False, noise=1.0, n_fine=64):
     S = importlib.import_module("spin-nerf_amd")
     RenderTrainer = importlib.import_module("spin-nerf_amd.train").RenderTrainer
     dev = torch.device("cuda")
     torch.manual_seed(seed)
     import tempfile
     args = argparse.Namespace(
-        multires=10, multires_views=4, i_embed=0, use_viewdirs=True, N_importance=64, N_samples=64,
+        multires=10, multires_views=4, i_embed=0, use_viewdirs=True, N_importance=n_fine, N_samples=64,
         alpha_model_path=None, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536,
         lrate=5e-4, basedir=tempfile.mkdtemp(), expname="", ft_path=None, no_reload=True, perturb=1.0,
         white_bkgd=white, raw_noise_std=noise, dataset_type="llff", no_ndc=True, lindisp=False, sigma_loss=False,
@@ -87,23 +87,27 @@ def test_bf16_training_matches_fp32_psnr():
     state: a 0 * NaN in the compositing backward of rays that hit nothing — fixed, test_gpu_kernels.py:
     test_composite_backward_of_a_ray_that_hits_nothing_is_finite.)
 
-    The per-step training PSNR of this scene swings by +-1.2 dB (standard deviation of a 50-step mean across seeds), so the
-    comparison is made on a long window.  Measured on MI355X (tests/probes/psnr_gap.py, profiles/r02_psnr_gap.txt): 4000
-    iterations, 12 seeds with independent batch sequences, paired by seed — mean of the last 500 steps bf16 32.88 dB, fp32
-    32.80 dB, paired difference +0.09 dB with standard error 0.12 (standard deviation of a single pair 0.43); the 500 steps
-    before: +0.04 +- 0.09: no gap at the measurement's resolution, consistent with BASELINE.json's +-0.1 dB.  This
-    test is the one-seed, 1200-iteration version of that: the last-400-step means within 0.8 dB (2 sd of a pair), and
-    both paths above 24 dB."""
-    iters = 1200
-    p32, t32 = train("fp32", iters)
-    s32 = train.seen_view_psnr
-    p16, t16 = train("bf16", iters)
-    s16 = train.seen_view_psnr
-    tail32, tail16 = float(np.mean(p32[-400:])), float(np.mean(p16[-400:]))
-    print(f"train PSNR (last 400 of {iters}): fp32 {tail32:.2f} dB, bf16 {tail16:.2f} dB; "
-          f"held-out view: fp32 {t32:.2f} dB, bf16 {t16:.2f} dB; start {np.mean(p32[:5]):.2f} dB")
-    print(f"deterministic full-frame render of a training camera: fp32 {s32:.2f} dB, bf16 {s16:.2f} dB")
-    assert s32 > 22.0 and s16 > 22.0, "the inference path does not reproduce what was trained"
-    assert tail32 > 24.0, "fp32 path did not learn the scene"
-    assert tail16 > 24.0, "bf16 path did not learn the scene"
-    assert abs(tail16 - tail32) < 0.8, (tail16, tail32)
+    The comparison is PAIRED by seed (same initial weights, ray batches and in-kernel draws for both precisions) and made
+    on the mean of the last 400 of 1200 steps.  Measured on MI355X over 12 seeds (round 3): paired difference bf16 - fp32
+    -0.00 dB, standard deviation of a pair 0.17 dB (largest 0.34); round 2's 4000-iteration, 12-seed run
+    (profiles/r02_psnr_gap.txt): +0.09 +- 0.12 dB.  Held-out views on a wider field of view, 64 + 128 samples:
+    profiles/r03_psnr_heldout.txt (+0.12 +- 0.24 dB over the pairs that end in the same basin).  Gates: the mean of four
+    pairs within 0.3 dB (3.5 standard errors), every pair within 0.8 dB, both paths above 24 dB — BASELINE.json asks for
+    +-0.1 dB on the statue scene, which is not in the container."""
+    iters, seeds = 1200, (0, 1, 2, 3)
+    diffs = []
+    for seed in seeds:
+        p32, t32 = train("fp32", iters, seed=seed)
+        s32 = train.seen_view_psnr
+        p16, t16 = train("bf16", iters, seed=seed)
+        s16 = train.seen_view_psnr
+        tail32, tail16 = float(np.mean(p32[-400:])), float(np.mean(p16[-400:]))
+        print(f"seed {seed}: train PSNR (last 400 of {iters}): fp32 {tail32:.2f} dB, bf16 {tail16:.2f} dB; deterministic full-frame "
+              f"render of a training camera: fp32 {s32:.2f} dB, bf16 {s16:.2f} dB; start {np.mean(p32[:5]):.2f} dB")
+        assert s32 > 22.0 and s16 > 22.0, "the inference path does not reproduce what was trained"
+        assert tail32 > 24.0, "fp32 path did not learn the scene"
+        assert tail16 > 24.0, "bf16 path did not learn the scene"
+        assert abs(tail16 - tail32) < 0.8, (seed, tail16, tail32)
+        diffs.append(tail16 - tail32)
+    print(f"paired differences bf16 - fp32: {[round(d, 3) for d in diffs]}, mean {np.mean(diffs):+.3f} dB")
+    assert abs(float(np.mean(diffs))) < 0.3, diffs
