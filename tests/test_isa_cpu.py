@@ -80,3 +80,12 @@ def test_checker_covers_asm_global_loads(tmp_path):
     assert chk.check(_listing(tmp_path, load + use)) == 1                       # consumed right away
     assert chk.check(_listing(tmp_path, load + dma * 3 + wait + use)) == 1      # only 3 loads behind it: vmcnt(6) proves nothing
     assert chk.check(_listing(tmp_path, load + dma * 7 + wait + use)) == 0      # 7 younger loads, at most 6 outstanding
+
+
+def test_checker_flags_a_valu_write_right_in_front_of_an_asm_mfma(tmp_path):
+    mfma = "        ;;#ASMSTART\n        v_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[4:7], a[0:15]\n        ;;#ASMEND\n"
+    mov = "        v_mov_b32_e32 v2, v30\n"
+    assert chk.check(_listing(tmp_path, mov + mfma)) == 1                       # no wait state in between
+    assert chk.check(_listing(tmp_path, mov + "        s_add_u32 s4, s4, 1\n" + mfma)) == 1     # one
+    assert chk.check(_listing(tmp_path, mov + "        s_nop 1\n" + mfma)) == 0                 # two
+    assert chk.check(_listing(tmp_path, "        v_mov_b32_e32 v9, v30\n" + mfma)) == 0         # another register

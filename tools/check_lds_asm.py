@@ -6,6 +6,10 @@ kernel linearly and reports any instruction that touches the destination of an a
 wait has covered it (LDS operations retire in order: a read is complete once a wait with
 N <= number of LDS reads issued after it has executed).  Branch targets are ignored (straight-line model).
 
+Second check, for the MFMAs issued from inline asm (the layer-pair weight-gradient kernel): the compiler's hazard
+recogniser does not look into asm, so a VALU instruction that writes one of an asm MFMA's source registers must be at
+least two wait states in front of it (an `s_nop N` counts N + 1; every other instruction counts one).
+
   python tools/check_lds_asm.py file.s   -> exit status 1 on a violation
 """
 import re, sys
@@ -25,10 +29,11 @@ def check(path):
     bad = 0
     kernel, pending, issued, in_asm = None, [], 0, False
     vpending = []   # asm global loads: [destination registers, line, vector-memory LOADS issued behind it]
+    recent = []     # the last instructions of the kernel, youngest last: (line, code)
     for ln, line in enumerate(open(path), 1):
         s = line.strip()
         if s.endswith(":") and s.startswith("_Z"):
-            kernel, pending, issued, vpending = s[:-1], [], 0, []
+            kernel, pending, issued, vpending, recent = s[:-1], [], 0, [], []
             continue
         if s.startswith(";;#ASMSTART"):
             in_asm = True; continue
@@ -36,7 +41,23 @@ def check(path):
             in_asm = False; continue
         if not s or s.startswith((";", ".", "//")) or kernel is None:
             continue
-        code = s.split(";")[0]
+        code = s.split(";")[0].strip()
+        if in_asm and code.startswith("v_mfma"):
+            srcs = set()
+            for o in code.split(None, 1)[1].split(",")[1:]:
+                srcs |= regs(o)
+            ws = 0
+            for l0, pc in reversed(recent):
+                if ws >= 2:
+                    break
+                if pc.startswith("s_nop"):
+                    ws += int(pc.split()[1]) + 1
+                    continue
+                if pc.startswith("v_") and not pc.startswith("v_mfma") and regs(pc.split(None, 1)[1].split(",")[0]) & srcs:
+                    print(f"{path}:{ln}: {kernel[:60]}: asm `{code[:50]}` reads a register `{pc[:50]}` (line {l0}) wrote {ws} wait states earlier")
+                    bad += 1
+                ws += 1
+        recent = (recent + [(ln, code)])[-4:]
         if in_asm and code.startswith("ds_read"):
             dst = regs(code.split(",")[0])
             issued += 1
