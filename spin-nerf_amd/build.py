@@ -59,7 +59,7 @@ def _keep_listings(verbose):
         if verbose or r.returncode:
             print(r.stdout.strip()[-2000:], flush=True)
         if r.returncode:
-            raise RuntimeError("check_lds_asm.py: an asm LDS read is consumed before its wait")
+            raise RuntimeError("check_lds_asm.py: an asm LDS read is consumed before its wait (or no kernel was recognised)")
 
 
 def build(force=False, verbose=True):

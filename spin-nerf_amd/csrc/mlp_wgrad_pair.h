@@ -63,6 +63,12 @@ struct PairArgs {
 };
 
 constexpr int kPairWaves = 4;
+#ifndef SNR_PAIR_M0_SPLIT
+#define SNR_PAIR_M0_SPLIT 1
+#endif
+#ifndef SNR_PAIR_BIAS_C
+#define SNR_PAIR_BIAS_C 1
+#endif
 #ifndef SNR_PAIR_PREFETCH
 #define SNR_PAIR_PREFETCH 0   // the next body's leading reads are issued by this body's tail as compiler-visible loads
 #endif
@@ -88,7 +94,7 @@ constexpr int kPairWaves = 4;
 // Every LDS read is issued LA steps ahead of its MFMAs, across the loop's back edge for the head.  Completion is counted:
 // LDS operations retire in order, so the wait in front of an even step (it covers the odd step behind it too) allows
 // exactly the reads issued since (PairProg::young_pair).
-enum { EV_ISSUE = 0, EV_FLAGS, EV_STEP_A, EV_STEP_B, EV_CVT, EV_SYNC, EV_DMA, EV_SUM, EV_SUMA, EV_ADVANCE, EV_PREFETCH };
+enum { EV_ISSUE = 0, EV_FLAGS, EV_STEP_A, EV_STEP_B, EV_CVT, EV_SYNC, EV_DMA, EV_SUM, EV_SUMA, EV_ADVANCE, EV_PREFETCH, EV_M0 };
 template <int TYPE, int KX> struct PairCfg {
   static constexpr bool PB = TYPE == 1;
   static constexpr int KR = PB ? 16 : KX;        // fragments of the rebuild's contraction
@@ -112,7 +118,7 @@ template <int TYPE, int KX> struct PairCfg {
 
 template <int TYPE, int KX> struct PairProg {
   using C = PairCfg<TYPE, KX>;
-  static constexpr int NS = C::NS, NM = C::NM, NR = C::NR, LA = C::LA, MAXEV = 6 * C::NS + 64;
+  static constexpr int NS = C::NS, NM = C::NM, NR = C::NR, LA = C::LA, MAXEV = 6 * C::NS + 96;
   int order[NS];   // >= 0: R-step q;  < 0: A-step ~e, e = t * NM + m
   int ip[NS];      // position (= "in front of step ip") at which the step's reads are issued; < 0: NS + ip of the previous body
   int kind[MAXEV], arg[MAXEV], nxt[MAXEV], n;
@@ -169,6 +175,9 @@ template <int TYPE, int KX> struct PairProg {
           if (p > 0 && order[p - 1] < 0 && !C::PB) push(EV_SUMA, 2 * (p - 1) + 1, 0);
           for (int i = 0; i < NS; ++i) if (ip[i] == p) push(EV_ISSUE, i, 0);
           if (SNR_PAIR_PREFETCH) for (int i = 0; i < NS; ++i) if (ip[i] < 0 && ip[i] + NS == p) push(EV_PREFETCH, i, 1);
+          // M0 of the DMA piece issued behind this step's second MFMA: written a gap ahead, the MFMA in between is the wait
+          // state the hardware wants between a scalar write of M0 and the LDS-DMA that reads it
+          if (SNR_PAIR_M0_SPLIT && p >= dma_step0 && p < adv_step0) push(EV_M0, p - dma_step0, 0);
         } else {
           push(EV_STEP_B, p, 0);
           if (p == C::SYNC_STEP) push(EV_SYNC, 0, 0);
@@ -240,26 +249,40 @@ template <int OFF> __device__ __forceinline__ void pair_read16u(u32x4& dst, uint
 #else
 #define SNR_PAIR_LGKM(N) ((N) < 15 ? (N) : 15)
 #endif
-template <int N> __device__ __forceinline__ void pair_wait(bf16x8& f) {
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(SNR_PAIR_LGKM(N)));
-}
-template <int N> __device__ __forceinline__ void pair_wait(bf16x4& a, bf16x4& b) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(SNR_PAIR_LGKM(N)));
-}
-template <int N> __device__ __forceinline__ void pair_wait(bf16x8& a, bf16x8& b) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(SNR_PAIR_LGKM(N)));
-}
-template <int N> __device__ __forceinline__ void pair_wait(bf16x8& a, bf16x4& b, bf16x4& c) {
-  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(SNR_PAIR_LGKM(N)));
-}
-template <int N> __device__ __forceinline__ void pair_wait(bf16x4& a, bf16x4& b, bf16x4& c, bf16x4& d) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(SNR_PAIR_LGKM(N)));
-}
-template <int N> __device__ __forceinline__ void pair_wait(u32x4& a, u32x4& b) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(SNR_PAIR_LGKM(N)));
-}
-template <int N> __device__ __forceinline__ void pair_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(SNR_PAIR_LGKM(N)));
+template <typename T> __device__ __forceinline__ void pair_wait_tie(T& r) { asm volatile("" : "+v"(r)); }
+// The waits name no registers.  Tying the covered registers to the statement ("+v") makes the compiler pad it: gfx950's
+// forwarding-hazard rule treats every inline asm that defines a register as a possible partial write, asks for one wait
+// state before the next reader, and counts other asm statements as zero wait states — an `s_nop 0` behind every wait in
+// front of its MFMA, 16 to 21 per body.  Without ties nothing but the statement order (asm volatile statements stay in
+// order, a sched_barrier closes every MFMA gap) keeps a reader behind its wait: tools/check_lds_asm.py proves on the
+// listing, at build time, that no instruction touches a register of an LDS read before a wait has covered it.
+#ifndef SNR_PAIR_WAIT_TIES
+#define SNR_PAIR_WAIT_TIES 2
+#endif
+#ifndef SNR_PAIR_WAIT_BUILTIN
+#define SNR_PAIR_WAIT_BUILTIN 1
+#endif
+#ifndef SNR_PAIR_WAIT_NOP
+#define SNR_PAIR_WAIT_NOP 0        // experiment: wait states behind the wait (0 / 1 / 2)
+#endif
+#ifndef SNR_PAIR_WAIT_NOP_KIND
+#define SNR_PAIR_WAIT_NOP_KIND 0   // 0: every wait, 1: waits that cover transposing reads, 2: waits that cover none
+#endif
+template <int N, typename... T> __device__ __forceinline__ void pair_wait(T&... regs) {
+#if SNR_PAIR_WAIT_TIES
+  (pair_wait_tie(regs), ...);
+#endif
+#if SNR_PAIR_WAIT_BUILTIN
+  __builtin_amdgcn_s_waitcnt(0xC07F | (SNR_PAIR_LGKM(N) << 8));   // vmcnt 63, expcnt 7: lgkmcnt only
+#else
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(SNR_PAIR_LGKM(N)) : "memory");
+#endif
+  constexpr bool has_tr = (std::is_same<T, bf16x4>::value || ...);
+  if constexpr (SNR_PAIR_WAIT_NOP > 0 && (SNR_PAIR_WAIT_NOP_KIND == 0 || (SNR_PAIR_WAIT_NOP_KIND == 1) == has_tr))
+    asm volatile("s_nop %0" ::"n"(SNR_PAIR_WAIT_NOP - 1));
+#if SNR_PAIR_WAIT_TIES == 1
+  (pair_wait_tie(regs), ...);
+#endif
 }
 
 // The 256 accumulator registers are the whole accumulator file of a one-wave-per-SIMD kernel; with the rebuild's own
@@ -281,6 +304,12 @@ __device__ __forceinline__ void pair_mfma_acc(f32x16& acc, const bf16x8& a, cons
 __device__ __forceinline__ void pair_mfma_reb_first(f32x16& r, const bf16x8& a, const bf16x8& b, u32x4& p0, u32x4& p1) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %3, %4, 0" : "=&v"(r), "+v"(p0), "+v"(p1) : "v"(a), "v"(b));
 }
+// kind A: C = the column's bias in all 16 registers (in the transposed tile a lane is one column of h_2k, so its bias is one
+// value per lane): the addition rides in the MFMA instead of costing a v_pk_add_f32 — and the wait state gfx950 wants
+// between that and the conversion that reads it — per packed word, 32 instructions a body
+__device__ __forceinline__ void pair_mfma_reb_first(f32x16& r, const bf16x8& a, const bf16x8& b, u32x4& p0, u32x4& p1, const f32x16& c) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %3, %4, %5" : "=&v"(r), "+v"(p0), "+v"(p1) : "v"(a), "v"(b), "v"(c));
+}
 __device__ __forceinline__ void pair_mfma_reb(f32x16& r, const bf16x8& a, const bf16x8& b) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(r) : "v"(a), "v"(b));
 }
@@ -291,11 +320,23 @@ __device__ __forceinline__ void pair_operand_ready(u32x4& b0, u32x4& b1) { asm v
 // work in place: left to the compiler the 16 words of a k-step are expanded into several dozen temporaries at once, and
 // the weight fragments are spilled to make room.
 //   keep the low / high bf16 of x where bit `bit` of w0 / w1 (the two samples' flag words) is set; w0, w1 are consumed
+#ifndef SNR_PAIR_FLAGS_ASM
+#define SNR_PAIR_FLAGS_ASM 0
+#endif
 __device__ __forceinline__ void pk_flags_extract(unsigned& w0, unsigned& w1, unsigned bit) {   // -> 0 / -1 each
+#if SNR_PAIR_FLAGS_ASM
   asm("v_bfe_i32 %0, %0, %2, 1\n\tv_bfe_i32 %1, %1, %2, 1" : "+v"(w0), "+v"(w1) : "v"(bit));
+#else
+  w0 = (unsigned)__builtin_amdgcn_sbfe((int)w0, bit, 1u);
+  w1 = (unsigned)__builtin_amdgcn_sbfe((int)w1, bit, 1u);
+#endif
 }
 __device__ __forceinline__ void pk_flags_apply(unsigned& x, unsigned& m0, unsigned m1) {   // low half by m0, high half by m1
+#if SNR_PAIR_FLAGS_ASM
   asm("v_bfi_b32 %1, %3, %1, %2\n\tv_and_b32 %0, %0, %1" : "+v"(x), "+v"(m0) : "v"(m1), "s"(0xffffu));
+#else
+  x &= __builtin_amdgcn_perm(m1, m0, 0x07060100u);   // bytes 3, 2 of m1 over bytes 1, 0 of m0
+#endif
 }
 //   sum += low bf16 + high bf16 of x  (v_dot2c_f32_bf16 against (1, 1): one instruction per word)
 __device__ __forceinline__ void pk_sum_bf16_2(float& sum, unsigned x0, unsigned x1) {
@@ -356,17 +397,6 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
 #if SNR_PAIR_ABLATE & 1
     if (issued > 2 * RING) return;
 #endif
-#ifdef SNR_PAIR_DMA_BUILTIN
-    char* sbase = smem + slot * SLOT;
-    if constexpr (k < C::NIX) {
-      __builtin_amdgcn_global_load_lds(xp + 4096 * k + lane16, SNR_LDS(sbase + C::XO + (wave + 4 * k) * 1024), 16, 0, 0);
-    } else if constexpr (k < C::NIX + C::NID) {
-      __builtin_amdgcn_global_load_lds(dp + 4096 * (k - C::NIX) + lane16, SNR_LDS(sbase + C::DZO + (wave + 4 * (k - C::NIX)) * 1024), 16, 0, 0);
-    } else if constexpr (PB && k == C::NIX + C::NID) {
-      __builtin_amdgcn_global_load_lds(fp + f_lane, SNR_LDS(sbase + C::FO + wave * 256), 4, 0, 0);
-    }
-    return;
-#endif
     if constexpr (k < C::NIX) {
       asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
                    :: "v"(voff[k]), "s"(sl), "n"(C::XO + 4096 * k), "s"(xp) : "scc");
@@ -374,12 +404,28 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
       asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
                    :: "v"(voff[k - C::NIX]), "s"(sl), "n"(C::DZO + 4096 * (k - C::NIX)), "s"(dp) : "scc");
     } else if constexpr (PB && k == C::NIX + C::NID) {
-#ifdef SNR_PAIR_FLAGS_BUILTIN
-      __builtin_amdgcn_global_load_lds(fp + f_lane, SNR_LDS(smem + slot * SLOT + C::FO + wave * 256), 4, 0, 0);
-#else
       issue_flags(sl);
-#endif
     }
+  };
+  // In the tile loop the two halves of a piece are separate events (EV_M0 in the gap in front of the step's second MFMA,
+  // the load behind it): the MFMA is the wait state, and the gap that takes the load holds one instruction, not three.
+  auto flags_m0 = [&](uint32_t sl) { asm volatile("s_add_u32 m0, %0, %1" :: "s"(sl), "s"(flag_w) : "scc"); };
+  auto flags_load = [&]() { asm volatile("global_load_lds_dword %0, %1" :: "v"(f_lane), "s"(fp)); };
+  auto piece_m0 = [&](int slot, auto K_) {
+    constexpr int k = decltype(K_)::value;
+    const uint32_t sl = lds_w + slot * SLOT;
+    if constexpr (k < C::NIX) asm volatile("s_add_u32 m0, %0, %1" :: "s"(sl), "n"(C::XO + 4096 * k) : "scc");
+    else if constexpr (k < C::NIX + C::NID) asm volatile("s_add_u32 m0, %0, %1" :: "s"(sl), "n"(C::DZO + 4096 * (k - C::NIX)) : "scc");
+    else if constexpr (PB && k == C::NIX + C::NID) flags_m0(sl);
+  };
+  auto piece_load = [&](auto K_) {
+    constexpr int k = decltype(K_)::value;
+#if SNR_PAIR_ABLATE & 1
+    if (issued > 2 * RING) return;
+#endif
+    if constexpr (k < C::NIX) asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(voff[k]), "s"(xp));
+    else if constexpr (k < C::NIX + C::NID) asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(voff[k - C::NIX]), "s"(dp));
+    else if constexpr (PB && k == C::NIX + C::NID) flags_load();
   };
   auto advance = [&]() {   // past the end the last tile is loaded again: every body issues the same NI instructions
     if (issued + 1 < t1) { ++issued; xp += xs; dp += dst_; fp += fs_; }
@@ -392,10 +438,17 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
 #pragma unroll
     for (int q = 0; q < KR; ++q)
       W[c][q] = *(const Frag*)(a.blob + (((int64_t)H.w_frag + (2 * wave + c) * KR + q) * 64 + lane) * 16);
-  float bias_j[2] = {0.f, 0.f};   // (a literal zero for kind B: the additions below disappear)
+  // kind A: the bias of this lane's column of h_2k, 16 copies = the C operand of the rebuild chain's first MFMA (opaque to the
+  // compiler, or it would re-materialise the copies in front of every use)
+  f32x16 biasC[2];
   if constexpr (!PB) {
-    bias_j[0] = a.bias[H.bias_off + 64 * wave + (lane & 31)];
-    bias_j[1] = a.bias[H.bias_off + 64 * wave + 32 + (lane & 31)];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float bj = a.bias[H.bias_off + 64 * wave + 32 * c + (lane & 31)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) biasC[c][r] = bj;
+      asm volatile("" : "+v"(biasC[c]));
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -460,7 +513,8 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
     constexpr int h = decltype(H_)::value, d = decltype(D_)::value, c = decltype(C_)::value, part = decltype(PART_)::value;
     if constexpr (!PB) {
       if constexpr (part == 0) {
-        cv = f32x2_t{R[c][8 * h + 2 * d], R[c][8 * h + 2 * d + 1]} + f32x2_t{bias_j[c], bias_j[c]};
+        cv = f32x2_t{R[c][8 * h + 2 * d], R[c][8 * h + 2 * d + 1]};   // (bias: the chain's C operand)
+        if constexpr (!SNR_PAIR_BIAS_C) cv += f32x2_t{biasC[c][0], biasC[c][0]};
       } else {
         unsigned x = __builtin_bit_cast(unsigned, __builtin_convertvector(cv, bf16x2_t));
 #if !(SNR_PAIR_ABLATE & 8)
@@ -543,7 +597,9 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
         if constexpr (o >= 0) {
           Frag& x = rf[arg % WIN];
           if constexpr (!(SNR_PAIR_ABLATE & 16) || o == 0) {
-            if constexpr (o == 0) pair_mfma_reb_first(R[c], x, W[c][0], P[0][1], P[1][1]);
+            if constexpr (o == 0 && PB) pair_mfma_reb_first(R[c], x, W[c][0], P[0][1], P[1][1]);
+            else if constexpr (o == 0 && SNR_PAIR_BIAS_C) pair_mfma_reb_first(R[c], x, W[c][0], P[0][1], P[1][1], biasC[c]);
+            else if constexpr (o == 0) pair_mfma_reb_first(R[c], x, W[c][0], P[0][1], P[1][1]);
             else pair_mfma_reb(R[c], x, W[c][o]);
           }
         } else {
@@ -587,8 +643,11 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
         convert_item(std::integral_constant<int, h>{}, std::integral_constant<int, d>{}, std::integral_constant<int, c>{},
                      std::integral_constant<int, part>{});
         __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (kind == EV_M0) {
+        piece_m0(islot, std::integral_constant<int, arg>{});
       } else if constexpr (kind == EV_DMA) {
-        issue_piece(islot, std::integral_constant<int, arg>{});
+        if constexpr (SNR_PAIR_M0_SPLIT) piece_load(std::integral_constant<int, arg>{});
+        else issue_piece(islot, std::integral_constant<int, arg>{});
       } else if constexpr (kind == EV_SUM) {
         if constexpr (!FIRST) pk_sum_bf16(bsum[arg % 2], P[arg % 2][arg / 2]);   // (k-step arg / 2, column block arg % 2)
         __builtin_amdgcn_sched_barrier(0);

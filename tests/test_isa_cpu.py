@@ -15,7 +15,8 @@ spec.loader.exec_module(chk)
 
 def _listing(tmp_path, body):
     p = tmp_path / "k.s"
-    p.write_text("_Z6kernelv:\n" + textwrap.dedent(body) + "\ts_endpgm\n")
+    # hipcc writes the kernel label with a trailing comment
+    p.write_text("_Z6kernelv:                             ; @_Z6kernelv\n" + textwrap.dedent(body) + "\ts_endpgm\n")
     return str(p)
 
 
@@ -62,7 +63,11 @@ def test_built_listings_are_clean():
     if not listings:
         pytest.skip("no device listing (run __graft_entry__.build() first)")
     for p in listings:
+        seen = chk.n_kernels[0]
         assert chk.check(p) == 0, p
+        # the kernels were recognised (for a round the label pattern missed hipcc's `name: ; @name` lines and the check
+        # passed on nothing)
+        assert chk.n_kernels[0] - seen >= 5, p
         txt = open(p).read()
         assert "ds_read_b128" in txt   # the listing really contains the asm reads
 
@@ -89,3 +94,16 @@ def test_checker_flags_a_valu_write_right_in_front_of_an_asm_mfma(tmp_path):
     assert chk.check(_listing(tmp_path, mov + "        s_add_u32 s4, s4, 1\n" + mfma)) == 1     # one
     assert chk.check(_listing(tmp_path, mov + "        s_nop 1\n" + mfma)) == 0                 # two
     assert chk.check(_listing(tmp_path, "        v_mov_b32_e32 v9, v30\n" + mfma)) == 0         # another register
+
+
+def test_checker_does_not_vouch_for_a_global_load_used_behind_a_branch(tmp_path):
+    body = """
+        ;;#ASMSTART
+        global_load_dwordx4 v[0:3], v8, s[2:3]
+        ;;#ASMEND
+        s_cbranch_scc1 .LBB0_2
+        v_and_b32_e32 v20, 0x10001, v1
+    """
+    before = chk.unverified[0]
+    assert chk.check(_listing(tmp_path, body)) == 0
+    assert chk.unverified[0] == before + 1
