@@ -69,6 +69,18 @@ constexpr int kPairWaves = 4;
 #ifndef SNR_PAIR_BIAS_C
 #define SNR_PAIR_BIAS_C 1
 #endif
+#ifndef SNR_PAIR_NTOP_A
+#define SNR_PAIR_NTOP_A 6
+#endif
+#ifndef SNR_PAIR_NTOP_B
+#define SNR_PAIR_NTOP_B 4
+#endif
+#ifndef SNR_PAIR_SUM8
+#define SNR_PAIR_SUM8 1
+#endif
+#ifndef SNR_PAIR_SWZ
+#define SNR_PAIR_SWZ 1
+#endif
 #ifndef SNR_PAIR_PREFETCH
 #define SNR_PAIR_PREFETCH 0   // the next body's leading reads are issued by this body's tail as compiler-visible loads
 #endif
@@ -160,7 +172,7 @@ template <int TYPE, int KX> struct PairProg {
     // places at a loop boundary (or a reuse of the register behind the loop) would meet the old register content.
     // (SNR_PAIR_PREFETCH: those reads are issued by the previous body's tail instead, as loads the compiler knows — it waits
     //  for them itself, at the loop head, and never touches a register they are due in)
-    const int n_top = SNR_PAIR_PREFETCH ? 0 : (C::PB ? 4 : 6);   // conversion micro-items at the top
+    const int n_top = SNR_PAIR_PREFETCH ? 0 : (C::PB ? SNR_PAIR_NTOP_B : SNR_PAIR_NTOP_A);   // conversion micro-items at the top
     if (!SNR_PAIR_PREFETCH) {
       if (C::PB) { push(EV_FLAGS, 2, 0); push(EV_FLAGS, 3, 0); }
       for (int i = 0; i < NS; ++i) if (ip[i] < 0) push(EV_ISSUE, i, 0);
@@ -184,7 +196,11 @@ template <int TYPE, int KX> struct PairProg {
           if (order[p] < 0 && !C::PB) push(EV_SUMA, 2 * p, 0);   // kind A: row sums of this A-step's operand (if the wave owns the rows),
           if (p >= dma_step0 && p < adv_step0) push(EV_DMA, p - dma_step0, 0);
           if (p >= adv_step0 && p < adv_step0 + 4) push(EV_ADVANCE, p - adv_step0, 0);
+#if SNR_PAIR_SUM8
+          if (C::PB && p >= dma_step0 && p < dma_step0 + 8) push(EV_SUM, p - dma_step0, 0);   // two words beside each DMA piece
+#else
           if (C::PB && p >= adv_step0 + 4 && p < adv_step0 + 8) push(EV_SUM, p - (adv_step0 + 4), 0);
+#endif
           if (C::PB && p == first_tail - 1) { push(EV_FLAGS, 0, 1); push(EV_FLAGS, 1, 1); }   // next tile's k-step 0 flags: the tail's conversion
         }
         // 16 conversion micro-items per half of R: item j = 2 d + c (packed word d of column block c), part 0 (add / convert)
@@ -381,9 +397,17 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
   // the scalar add clobbers SCC, which the compiler may hold live across the statement (found as intermittent garbage).
   // (No LDS read may sit in the cycle in front of an LDS-DMA — mlp_device.h, Pipe::issue_one: the schedule places every
   //  piece behind a step's second MFMA, the prologue's behind nothing.)
-  uint32_t voff[4];
+  // The section the rebuild reads with ds_read_b128 (X in kind A, D in kind B) is stored with the two 16-byte halves of the
+  // samples 16..31 of every fragment swapped: a b128 read is served in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
+  // (+ 32), and with the halves as stored by the forward pass (chunk 2 s + half) a group touches only every other 16-byte
+  // bank quad — twice: a 2-way conflict on every rebuild read.  The DMA does the swap on the way in (its lanes 32..63 fetch
+  // the neighbouring chunk; the global side stays inside the same 1 KiB), the reading lanes undo it in their address.
+  uint32_t voff[4], voffs[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) voff[k] = lane16 + 4096u * k;
+  for (int k = 0; k < 4; ++k) {
+    voff[k] = lane16 + 4096u * k;
+    voffs[k] = SNR_PAIR_SWZ ? ((uint32_t)(lane ^ (lane >> 5)) * 16u + 4096u * k) : voff[k];
+  }
   const uint32_t lds_w = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);
   // (the flag KiB: four bytes per lane, gathered into the [g][word][s] image; this wave's quarter starts 256 wave bytes in:
   //  lds_w holds 1024 wave)
@@ -399,10 +423,10 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
 #endif
     if constexpr (k < C::NIX) {
       asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
-                   :: "v"(voff[k]), "s"(sl), "n"(C::XO + 4096 * k), "s"(xp) : "scc");
+                   :: "v"(PB ? voff[k] : voffs[k]), "s"(sl), "n"(C::XO + 4096 * k), "s"(xp) : "scc");
     } else if constexpr (k < C::NIX + C::NID) {
       asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
-                   :: "v"(voff[k - C::NIX]), "s"(sl), "n"(C::DZO + 4096 * (k - C::NIX)), "s"(dp) : "scc");
+                   :: "v"(PB ? voffs[k - C::NIX] : voff[k - C::NIX]), "s"(sl), "n"(C::DZO + 4096 * (k - C::NIX)), "s"(dp) : "scc");
     } else if constexpr (PB && k == C::NIX + C::NID) {
       issue_flags(sl);
     }
@@ -423,8 +447,8 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
 #if SNR_PAIR_ABLATE & 1
     if (issued > 2 * RING) return;
 #endif
-    if constexpr (k < C::NIX) asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(voff[k]), "s"(xp));
-    else if constexpr (k < C::NIX + C::NID) asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(voff[k - C::NIX]), "s"(dp));
+    if constexpr (k < C::NIX) asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(PB ? voff[k] : voffs[k]), "s"(xp));
+    else if constexpr (k < C::NIX + C::NID) asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(PB ? voffs[k - C::NIX] : voff[k - C::NIX]), "s"(dp));
     else if constexpr (PB && k == C::NIX + C::NID) flags_load();
   };
   auto advance = [&]() {   // past the end the last tile is loaded again: every body issues the same NI instructions
@@ -460,7 +484,8 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
   // rebuild A operand: lane (sample s = lane & 31, k-half gg) reads its 16 bytes of fragment q (row act_row(s, q))
   const int s32 = lane & 31, gg = lane >> 5;
   const uint32_t lds0 = lds_addr(smem);
-  const uint32_t rdE = C::RO + gg * 16 + s32 * 32, rdO = C::RO + gg * 16 + (s32 ^ 4) * 32;
+  const int ggs = SNR_PAIR_SWZ ? (gg ^ (s32 >> 4)) : gg;   // (the swapped halves of samples 16..31, see the DMA offsets)
+  const uint32_t rdE = C::RO + ggs * 16 + s32 * 32, rdO = C::RO + ggs * 16 + (s32 ^ 4) * 32;
   // accumulation A operand (transposing reads, mlp_wgrad.h): 16-lane group (gg, bh) receives neuron column ip of the
   // [4 samples][16 neurons] block of fragment 2 m + bh whose samples are 16 t + 8 q + 4 gg + 0..3 — the k-slot order the
   // rebuilt C tile implies: register 8 t + e of lane half gg holds sample 16 t + 8 (e >> 2) + 4 gg + (e & 3)
@@ -649,7 +674,14 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
         if constexpr (SNR_PAIR_M0_SPLIT) piece_load(std::integral_constant<int, arg>{});
         else issue_piece(islot, std::integral_constant<int, arg>{});
       } else if constexpr (kind == EV_SUM) {
+#if SNR_PAIR_SUM8
+        if constexpr (!FIRST) {   // (k-step arg / 4, column block arg % 2, words 2 q, 2 q + 1 with q = arg / 2 % 2)
+          const u32x4& w = P[arg % 2][arg / 4];
+          pk_sum_bf16_2(bsum[arg % 2], w[2 * (arg / 2 % 2)], w[2 * (arg / 2 % 2) + 1]);
+        }
+#else
         if constexpr (!FIRST) pk_sum_bf16(bsum[arg % 2], P[arg % 2][arg / 2]);   // (k-step arg / 2, column block arg % 2)
+#endif
         __builtin_amdgcn_sched_barrier(0);
       } else if constexpr (kind == EV_SUMA) {
         // kind A, bias gradient of layer 2k+1: the wave sums the rows of its two row tiles (the step's operand registers are
@@ -681,7 +713,7 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
     advance();
   }
   body(std::true_type{});
-  for (int64_t tile = 0; tile < t1; ++tile) body(std::false_type{});
+  for (int tile = 0, nt = (int)t1; tile < nt; ++tile) body(std::false_type{});
   // trailing DMA loads; 12+ wait states from the last MFMA to the accumulator reads
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
@@ -794,7 +826,7 @@ inline PairPlan make_pair_plan(const snr_mlp_config* c, int64_t n_samples, int64
   int n_slots = cus / 2;
   if (const char* e = getenv("SNR_PAIR_SLOTS")) n_slots = atoi(e) > 0 ? atoi(e) : n_slots;
   if (n_slots < kMaxPairs) n_slots = kMaxPairs;
-  int w0 = 66;   // cost of pair 0 relative to 100 of the others
+  int w0 = 80;   // cost of pair 0 relative to 100 of the others (swept on the GPU: 66 .. 86, profiles/r03_pair_tuning.txt)
   if (const char* e = getenv("SNR_PAIR_W0")) w0 = atoi(e) > 0 ? atoi(e) : w0;
   const int wsum = w0 + 300;
   int splits[kMaxPairs];

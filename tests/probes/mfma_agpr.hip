@@ -16,6 +16,15 @@ __global__ __launch_bounds__(256) void k(int iters, float* out) {
   for (int i = 0; i < 16; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) R[i][r] = 0.f;
   bf16x8 a = {1, 1, 1, 1, 1, 1, 1, 1}, b = a;
+  if (iters < 0) {   // random operands (a hash of lane and slot): what the clock does when the multipliers see real data
+    iters = -iters;
+    for (int i = 0; i < 8; ++i) {
+      unsigned h = (threadIdx.x * 8 + i + blockIdx.x * 2048) * 2654435761u;
+      a[i] = (__bf16)(((h >> 8) & 0xffff) / 32768.f - 1.f);
+      h *= 2246822519u;
+      b[i] = (__bf16)(((h >> 8) & 0xffff) / 32768.f - 1.f);
+    }
+  }
   unsigned x0 = threadIdx.x, x1 = 1, x2 = 2, x3 = 3;
   bf16x8 ld;
   const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (threadIdx.x & 63) * 16;
@@ -49,17 +58,18 @@ __global__ __launch_bounds__(256) void k(int iters, float* out) {
   if (s == 1234.5f) out[0] = s;
 }
 
-template <int MODE, int F> void run(const char* name, float* out) {
-  const int iters = 2000;
+// G workgroups (one per CU): the same loop on a part of the chip shows what the clock does under load
+template <int MODE, int F> void run(const char* name, float* out, int G = 256, bool random = false) {
+  const int iters = random ? -2000 : 2000;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  k<MODE, F><<<256, 256>>>(10, out);
+  k<MODE, F><<<G, 256>>>(random ? -10 : 10, out);
   hipEventRecord(e0);
-  k<MODE, F><<<256, 256>>>(iters, out);
+  k<MODE, F><<<G, 256>>>(iters, out);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  const double per = ms * 1e-3 / (iters * 64.0);
-  printf("%-44s fillers/MFMA %d: %.2f ns per MFMA = %.1f clk @2.4 GHz (%.0f TFLOP/s chip)\n", name, F, per * 1e9, per * 2.4e9,
-         256.0 * 4 * 32768 / per / 1e12);
+  const double per = ms * 1e-3 / (2000 * 64.0);
+  printf("%-44s %3d workgroups, fillers/MFMA %d: %.2f ns per MFMA = %.1f clk @2.4 GHz (%.0f TFLOP/s on those CUs)\n", random ? "alternating, random operands" : name, G, F,
+         per * 1e9, per * 2.4e9, G * 4.0 * 32768 / per / 1e12);
 }
 
 int main() {
@@ -74,5 +84,9 @@ int main() {
   run<0, 5>("alternating", out);
   run<0, 6>("alternating", out);
   run<1, 4>("accumulator-file tiles only", out);
+  for (int G : {16, 32, 64, 128, 192, 256}) run<0, 0>("alternating", out, G);
+  for (int G : {16, 32, 64, 128, 192, 256}) run<0, 4>("alternating", out, G);
+  for (int G : {32, 128, 256}) run<0, 0>("", out, G, true);
+  for (int G : {32, 128, 256}) run<0, 4>("", out, G, true);
   return 0;
 }

@@ -1,9 +1,14 @@
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 B="python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-frame --no-hashgrid --blocks 3"
-timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_render.py tests/test_gpu_train_step.py tests/test_gpu_edge_sizes.py -q -x --timeout 600 > gpurun_out/ab_tests.txt 2>&1; tail -3 gpurun_out/ab_tests.txt
+VARS="${VARS:-base new}"
+export SNR_PAIR_W0=80
+for v in $VARS; do
+  if [ $v = new ]; then unset SNR_LIB; else export SNR_LIB=$PWD/spin-nerf_amd/lib/ablate/libspinnerf_hip_$v.so; fi
+  echo "== $v: $(timeout 300 python -m pytest tests/test_gpu_kernels.py -q -x -k 'mlp_backward_bf16' 2>&1 | tail -1)" | tee -a gpurun_out/ab_result.txt
+done
 for i in 1 2; do
-  for v in base new; do
-    if [ $v = base ]; then export SNR_LIB=$PWD/spin-nerf_amd/lib/ablate/libspinnerf_hip_base.so; else unset SNR_LIB; fi
+  for v in $VARS; do
+    if [ $v = new ]; then unset SNR_LIB; else export SNR_LIB=$PWD/spin-nerf_amd/lib/ablate/libspinnerf_hip_$v.so; fi
     timeout 300 $B 2>/dev/null | python -c "
 import sys,json
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); k=d['kernels']

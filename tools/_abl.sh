@@ -1,0 +1,10 @@
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-frame --no-hashgrid --blocks 1"
+for v in $VARS; do
+  export SNR_LIB=$PWD/spin-nerf_amd/lib/ablate/libspinnerf_hip_$v.so
+  timeout 300 $B 2>/dev/null | python -c "
+import sys,json
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); k=d['kernels']
+print('$v', round(d['ms_per_step'],4), 'pair', round(k['mlp_wgrad_pair']['ms_per_step'],4))
+" | tee -a gpurun_out/abl_result.txt
+done
