@@ -60,6 +60,10 @@ struct PairArgs {
   float* part;
   int64_t n_tiles;
   int only_kind, only_pair;   // timing experiments (SNR_PAIR_KIND / SNR_PAIR_PAIR): -1 = all
+  // pacing of the two kinds of a slot (see pair_run): progress words behind the partial sums, one per slot
+  int64_t sync_off;           // float offset of the words inside `part`
+  int epoch;                  // launch counter (12 bits): a word of another launch reads as "no progress yet"
+  int sync_period, sync_lead; // kind A looks every sync_period tiles and waits while it is more than sync_lead tiles ahead; 0 = off
 };
 
 constexpr int kPairWaves = 4;
@@ -568,6 +572,9 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
     if constexpr (d == 3 && c == 1 && part == 1) pair_operand_ready(P[0][h], P[1][h]);
   };
 
+  unsigned* sync_w = (unsigned*)(a.part + a.sync_off) + (J.slot_begin + split);   // this slot's progress word (pacing)
+  unsigned post_word = 0, post_zero = 0;   // (VGPRs: the store's data and its zero offset)
+  asm volatile("" : "+v"(post_zero));
   // One body.  FIRST = body -1: rebuilds tile 0, accumulates nothing.
   auto body = [&](auto FIRST_) {
     constexpr bool FIRST = decltype(FIRST_)::value;
@@ -655,6 +662,10 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
         __builtin_amdgcn_s_barrier();
 #endif
         asm volatile("" ::: "memory");
+        // kind B's progress word (pacing, see the tile loop): right behind the wait, so that the store — vmcnt counts it, in
+        // order with the DMA pieces — has a whole body to complete before the next counted wait looks at the queue
+        // (unconditional: a branch here would cut the body into two scheduling regions)
+        if constexpr (PB && !FIRST) asm volatile("global_store_dword %0, %1, %2" :: "v"(post_zero), "v"(post_word), "s"(sync_w));
       } else if constexpr (kind == EV_CVT) {
         constexpr int h = arg / 16, j = (arg % 16) / 2, part = arg % 2, d = j / 2, c = j % 2;
         static_assert(d < 4 && h < 2, "conversion item out of range");
@@ -713,7 +724,33 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
     advance();
   }
   body(std::true_type{});
-  for (int tile = 0, nt = (int)t1; tile < nt; ++tile) body(std::false_type{});
+  // Pacing.  The two workgroups of a slot (kinds A and B, same XCD) stream the same tiles, and the second one to ask finds them
+  // in L2 — as long as it asks soon enough: the XCD's 4 MiB hold about seven tiles per slot.  Kind A's body is a fifth
+  // shorter than kind B's, so left alone it runs away and every tile is fetched from HBM twice (FETCH_SIZE 0.78 GB per
+  // launch instead of 0.55).  Kind B therefore posts its tile counter (one store per body, behind the body's barrier),
+  // and kind A looks at it every sync_period tiles — a load and a full vmcnt(0), at the loop head where nothing else is in
+  // flight that it could disturb — and sleeps while it is more than sync_lead tiles ahead.  Kind A has the time: the launch
+  // ends when kind B does.  The wait is bounded (a kind-B workgroup that is not resident yet must not hang the launch):
+  // after 256 looks without progress kind A stops looking for the rest of the launch.
+  bool pacing = a.sync_period > 0 && a.only_kind < 0;
+  for (int tile = 0, nt = (int)t1; tile < nt; ++tile) {
+    if constexpr (PB) {
+      post_word = ((unsigned)a.epoch << 20) | (unsigned)tile;   // (stored behind this body's barrier: EV_SYNC)
+    } else if (pacing) {
+      if (tile % a.sync_period == a.sync_period - 1) {
+        for (int look = 0;; ++look) {
+          unsigned w;
+          asm volatile("global_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(0u), "s"(sync_w) : "memory");
+          w = __builtin_amdgcn_readfirstlane(w);
+          const int theirs = (int)(w >> 20) == a.epoch ? (int)(w & 0xfffffu) : -1;
+          if (tile - theirs <= a.sync_lead) break;
+          if (look == 256) { pacing = false; break; }
+          __builtin_amdgcn_s_sleep(32);
+        }
+      }
+    }
+    body(std::false_type{});
+  }
   // trailing DMA loads; 12+ wait states from the last MFMA to the accumulator reads
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
@@ -882,6 +919,11 @@ inline PairPlan make_pair_plan(const snr_mlp_config* c, int64_t n_samples, int64
   }
   R.n_jobs = nj; R.n_outs = no;
   Pl.grid = 16 * ((slot + 7) / 8);   // slot p = workgroups 16 (p / 8) + p % 8 and + 8
+  A.sync_off = po; po += 256;   // progress words of the slots (pacing of the two kinds)
+  static int launch_epoch = 0;
+  A.epoch = (launch_epoch = (launch_epoch + 1) & 0xfff);
+  A.sync_period = getenv("SNR_PAIR_POLL") ? atoi(getenv("SNR_PAIR_POLL")) : 16;
+  A.sync_lead = getenv("SNR_PAIR_LEAD") ? atoi(getenv("SNR_PAIR_LEAD")) : 2;
   Pl.part_floats = po - part_base;
   return Pl;
 }
