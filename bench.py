@@ -406,6 +406,18 @@ def main():
                                          "achieved": mf * evals_per_step / (kernels[dom]["ms_per_step"] * 1e-3) / 1e12,
                                          "frac": mf * evals_per_step / (kernels[dom]["ms_per_step"] * 1e-3) / 1e12 / peak,
                                          "note": "incl. the recomputed layers; `achieved` above counts algorithmic FLOPs only"}
+            # what a dense bf16 MFMA stream reaches on this part with every CU busy and real data in the multipliers
+            # (tests/probes/mfma_agpr.hip; the file is this round's record of it — absent file: null, no literal)
+            ms_file = os.path.join(ROOT, "profiles", "r03_mfma_agpr.txt")
+            if os.path.exists(ms_file):
+                import re
+                m = re.search(r"random operands\s+256 workgroups, fillers/MFMA 0:.*?\((\d+) TFLOP/s", open(ms_file).read())
+                if m:
+                    roofline["mfma_executed"]["clock_limited_stream"] = {
+                        "tflops": float(m.group(1)), "frac_of_it": roofline["mfma_executed"]["achieved"] / float(m.group(1)),
+                        "source": "profiles/r03_mfma_agpr.txt",
+                        "note": "measured rate of a pure v_mfma_f32_32x32x16_bf16 stream, random operands, 256 CUs: the part clocks "
+                                "down under this load; `peak` stays the data-sheet 2.5 PFLOP/s"}
         roofline["stream"] = {"bytes_per_launch": stream_bytes[dom] * evals_per_step / launches,
                               "achieved": kernels[dom]["stream_GBps"], "peak": 8000.0, "unit": "GB/s",
                               "frac": kernels[dom]["stream_GBps"] / 8000.0}

@@ -11,8 +11,9 @@
 //
 // A layer's 256 x 256 fp32 accumulator is half of a CU's register file, so the two kinds cannot share a workgroup; they
 // share the HBM fetch instead: the workgroups b and b ^ 8 run on the same XCD (block b -> XCD b % 8) and sweep the same
-// tiles at the same pace, so the second request of a tile is an L2 hit (tests/probes/l2_share.hip: two such workgroups
-// are served 12 TB/s of requests out of 6 TB/s of HBM).  Per sample and layer pair: 1 KB written by the chain kernels
+// tiles at the same pace (kind A, whose body is shorter, paces itself on kind B's progress word: see the tile loop), so
+// the second request of a tile is an L2 hit (tests/probes/l2_share.hip: two such workgroups are served 12 TB/s of
+// requests out of 6 TB/s of HBM).  Per sample and layer pair: 1 KB written by the chain kernels
 // and ~1 KB fetched here, against 4 KB + 4 KB without the recompute.  The price is twice the MFMAs of the plain pass —
 // this kernel is bound by the matrix pipe, not by the stream — so its shape is chosen for MFMA issue:
 //
@@ -67,20 +68,11 @@ struct PairArgs {
 };
 
 constexpr int kPairWaves = 4;
-#ifndef SNR_PAIR_M0_SPLIT
-#define SNR_PAIR_M0_SPLIT 1
-#endif
-#ifndef SNR_PAIR_BIAS_C
-#define SNR_PAIR_BIAS_C 1
-#endif
 #ifndef SNR_PAIR_NTOP_A
 #define SNR_PAIR_NTOP_A 6
 #endif
 #ifndef SNR_PAIR_NTOP_B
 #define SNR_PAIR_NTOP_B 4
-#endif
-#ifndef SNR_PAIR_SUM8
-#define SNR_PAIR_SUM8 1
 #endif
 #ifndef SNR_PAIR_SWZ
 #define SNR_PAIR_SWZ 1
@@ -169,7 +161,7 @@ template <int TYPE, int KX> struct PairProg {
     const int lo_gap0 = 2 * first_tail + 1;          // first gap behind the tail's first step (two MFMAs behind the last R MFMA)
     const int lo_gaps = G - lo_gap0;
     const int dma_step0 = C::LEADA;                  // DMA pieces: behind MFMA b of the middle's steps
-    const int adv_step0 = dma_step0 + C::NI;         // then the pointer updates (3 parts), then kind B's column sums (4 parts)
+    const int adv_step0 = dma_step0 + C::NI;         // then the pointer updates (4 parts); kind B's column sums sit beside the first 8 pieces
     // Top of the body, in front of the first MFMA: the reads of the leading steps and of kind B's k-step-1 flag words, then
     // the first conversion items (they need no LDS data: the wait for the reads falls behind them).  No asm read is ever in
     // flight across the loop's back edge or at its exit: for the compiler such a read is complete when issued, and a copy it
@@ -193,18 +185,14 @@ template <int TYPE, int KX> struct PairProg {
           if (SNR_PAIR_PREFETCH) for (int i = 0; i < NS; ++i) if (ip[i] < 0 && ip[i] + NS == p) push(EV_PREFETCH, i, 1);
           // M0 of the DMA piece issued behind this step's second MFMA: written a gap ahead, the MFMA in between is the wait
           // state the hardware wants between a scalar write of M0 and the LDS-DMA that reads it
-          if (SNR_PAIR_M0_SPLIT && p >= dma_step0 && p < adv_step0) push(EV_M0, p - dma_step0, 0);
+          if (p >= dma_step0 && p < adv_step0) push(EV_M0, p - dma_step0, 0);
         } else {
           push(EV_STEP_B, p, 0);
           if (p == C::SYNC_STEP) push(EV_SYNC, 0, 0);
           if (order[p] < 0 && !C::PB) push(EV_SUMA, 2 * p, 0);   // kind A: row sums of this A-step's operand (if the wave owns the rows),
           if (p >= dma_step0 && p < adv_step0) push(EV_DMA, p - dma_step0, 0);
           if (p >= adv_step0 && p < adv_step0 + 4) push(EV_ADVANCE, p - adv_step0, 0);
-#if SNR_PAIR_SUM8
           if (C::PB && p >= dma_step0 && p < dma_step0 + 8) push(EV_SUM, p - dma_step0, 0);   // two words beside each DMA piece
-#else
-          if (C::PB && p >= adv_step0 + 4 && p < adv_step0 + 8) push(EV_SUM, p - (adv_step0 + 4), 0);
-#endif
           if (C::PB && p == first_tail - 1) { push(EV_FLAGS, 0, 1); push(EV_FLAGS, 1, 1); }   // next tile's k-step 0 flags: the tail's conversion
         }
         // 16 conversion micro-items per half of R: item j = 2 d + c (packed word d of column block c), part 0 (add / convert)
@@ -270,39 +258,18 @@ template <int OFF> __device__ __forceinline__ void pair_read16u(u32x4& dst, uint
 #define SNR_PAIR_LGKM(N) ((N) < 15 ? (N) : 15)
 #endif
 template <typename T> __device__ __forceinline__ void pair_wait_tie(T& r) { asm volatile("" : "+v"(r)); }
-// The waits name no registers.  Tying the covered registers to the statement ("+v") makes the compiler pad it: gfx950's
-// forwarding-hazard rule treats every inline asm that defines a register as a possible partial write, asks for one wait
-// state before the next reader, and counts other asm statements as zero wait states — an `s_nop 0` behind every wait in
-// front of its MFMA, 16 to 21 per body.  Without ties nothing but the statement order (asm volatile statements stay in
-// order, a sched_barrier closes every MFMA gap) keeps a reader behind its wait: tools/check_lds_asm.py proves on the
-// listing, at build time, that no instruction touches a register of an LDS read before a wait has covered it.
-#ifndef SNR_PAIR_WAIT_TIES
-#define SNR_PAIR_WAIT_TIES 2
-#endif
-#ifndef SNR_PAIR_WAIT_BUILTIN
-#define SNR_PAIR_WAIT_BUILTIN 1
-#endif
-#ifndef SNR_PAIR_WAIT_NOP
-#define SNR_PAIR_WAIT_NOP 0        // experiment: wait states behind the wait (0 / 1 / 2)
-#endif
-#ifndef SNR_PAIR_WAIT_NOP_KIND
-#define SNR_PAIR_WAIT_NOP_KIND 0   // 0: every wait, 1: waits that cover transposing reads, 2: waits that cover none
-#endif
+// The wait and its registers.  A wait whose asm statement itself carries the covered registers ("+v") is padded by the
+// compiler: gfx950's forwarding-hazard rule treats every inline asm that defines a register as a possible partial write,
+// asks for one wait state before the next reader, and counts other asm statements as zero wait states — an `s_nop 0`
+// behind every wait in front of its MFMA, 16 to 21 per body.  No tie at all is wrong: the destination of a read whose
+// result the compiler sees no use for (body -1 issues the accumulation reads and skips their MFMAs) is handed to the next
+// temporary while the read is in flight (garbage on the GPU; tools/check_lds_asm.py flags 121 places in that build).  So:
+// the registers are tied in an empty statement IN FRONT of a compiler-visible s_waitcnt — they stay allocated up to the
+// wait, the wait itself is the wait state the hazard rule wants, and the readers (asm volatile MFMAs, or VALU code behind
+// the gap's sched_barrier) cannot move above it.  The checker proves the result on the listing at build time.
 template <int N, typename... T> __device__ __forceinline__ void pair_wait(T&... regs) {
-#if SNR_PAIR_WAIT_TIES
   (pair_wait_tie(regs), ...);
-#endif
-#if SNR_PAIR_WAIT_BUILTIN
-  __builtin_amdgcn_s_waitcnt(0xC07F | (SNR_PAIR_LGKM(N) << 8));   // vmcnt 63, expcnt 7: lgkmcnt only
-#else
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(SNR_PAIR_LGKM(N)) : "memory");
-#endif
-  constexpr bool has_tr = (std::is_same<T, bf16x4>::value || ...);
-  if constexpr (SNR_PAIR_WAIT_NOP > 0 && (SNR_PAIR_WAIT_NOP_KIND == 0 || (SNR_PAIR_WAIT_NOP_KIND == 1) == has_tr))
-    asm volatile("s_nop %0" ::"n"(SNR_PAIR_WAIT_NOP - 1));
-#if SNR_PAIR_WAIT_TIES == 1
-  (pair_wait_tie(regs), ...);
-#endif
+  __builtin_amdgcn_s_waitcnt(0xC07F | (SNR_PAIR_LGKM(N) << 8));   // vmcnt 63, expcnt 7: lgkmcnt(N) only
 }
 
 // The 256 accumulator registers are the whole accumulator file of a one-wave-per-SIMD kernel; with the rebuild's own
@@ -336,38 +303,22 @@ __device__ __forceinline__ void pair_mfma_reb(f32x16& r, const bf16x8& a, const 
 __device__ __forceinline__ void pair_r_complete(f32x16& r0, f32x16& r1) { asm volatile("s_nop 7\n\ts_nop 4" : "+v"(r0), "+v"(r1)); }
 __device__ __forceinline__ void pair_operand_ready(u32x4& b0, u32x4& b1) { asm volatile("s_nop 1" : "+v"(b0), "+v"(b1)); }
 
-// Kind B's finishing touches on one packed word (two samples of one neuron column), as fixed instruction sequences that
-// work in place: left to the compiler the 16 words of a k-step are expanded into several dozen temporaries at once, and
-// the weight fragments are spilled to make room.
-//   keep the low / high bf16 of x where bit `bit` of w0 / w1 (the two samples' flag words) is set; w0, w1 are consumed
-#ifndef SNR_PAIR_FLAGS_ASM
-#define SNR_PAIR_FLAGS_ASM 0
-#endif
+// Kind B's finishing touches on one packed word (two samples of one neuron column): keep the low / high bf16 of x where bit
+// `bit` of w0 / w1 (the two samples' flag words) is set.  Compiler-visible (v_bfe_i32 x2, v_perm_b32, v_and_b32): as inline
+// asm the same four instructions needed copies of the flag words (they work in place) and a forwarding-hazard pad each;
+// the schedule's sched_barriers keep the compiler from expanding a k-step's 16 words at once, which is what made asm
+// necessary before the micro-items were pinned gap by gap.
 __device__ __forceinline__ void pk_flags_extract(unsigned& w0, unsigned& w1, unsigned bit) {   // -> 0 / -1 each
-#if SNR_PAIR_FLAGS_ASM
-  asm("v_bfe_i32 %0, %0, %2, 1\n\tv_bfe_i32 %1, %1, %2, 1" : "+v"(w0), "+v"(w1) : "v"(bit));
-#else
   w0 = (unsigned)__builtin_amdgcn_sbfe((int)w0, bit, 1u);
   w1 = (unsigned)__builtin_amdgcn_sbfe((int)w1, bit, 1u);
-#endif
 }
 __device__ __forceinline__ void pk_flags_apply(unsigned& x, unsigned& m0, unsigned m1) {   // low half by m0, high half by m1
-#if SNR_PAIR_FLAGS_ASM
-  asm("v_bfi_b32 %1, %3, %1, %2\n\tv_and_b32 %0, %0, %1" : "+v"(x), "+v"(m0) : "v"(m1), "s"(0xffffu));
-#else
   x &= __builtin_amdgcn_perm(m1, m0, 0x07060100u);   // bytes 3, 2 of m1 over bytes 1, 0 of m0
-#endif
 }
 //   sum += low bf16 + high bf16 of x  (v_dot2c_f32_bf16 against (1, 1): one instruction per word)
 __device__ __forceinline__ void pk_sum_bf16_2(float& sum, unsigned x0, unsigned x1) {
   asm("v_dot2c_f32_bf16 %0, %3, %1\n\tv_dot2c_f32_bf16 %0, %3, %2" : "+v"(sum) : "v"(x0), "v"(x1), "s"(0x3f803f80u));
 }
-//   (four words per statement: the compiler pads every asm statement whose output the next instruction reads)
-__device__ __forceinline__ void pk_sum_bf16(float& sum, const u32x4& x) {
-  asm("v_dot2c_f32_bf16 %0, %5, %1\n\tv_dot2c_f32_bf16 %0, %5, %2\n\tv_dot2c_f32_bf16 %0, %5, %3\n\tv_dot2c_f32_bf16 %0, %5, %4"
-      : "+v"(sum) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "s"(0x3f803f80u));
-}
-
 // WV: the wave index as a compile-time constant (kind A: which row tiles' sums this wave keeps is decided without branches)
 template <int TYPE, int KX, int WV>
 __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, int split, char* smem, int wave, int lane) {
@@ -395,7 +346,7 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
   const uint32_t f_lane = (uint32_t)((((fd >> 7) * 32 + (fd & 31)) * 4 + ((fd >> 5) & 3)) * 4);
   int64_t issued = 0;   // tiles issued so far
   bool go = false;
-  // One statement per piece: M0 = LDS destination of the wave's 1 KiB (the hardware adds lane x 16), a wait state, the
+  // (Prologue) one statement per piece: M0 = LDS destination of the wave's 1 KiB (the hardware adds lane x 16), a wait state, the
   // load with a wave-uniform 64-bit base + a 32-bit lane offset (lane16 + 4096 k lives in four registers: no address
   // arithmetic per piece).  M0 is written in the statement that reads it (the compiler does not preserve it around asm);
   // the scalar add clobbers SCC, which the compiler may hold live across the statement (found as intermittent garbage).
@@ -543,7 +494,6 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
     if constexpr (!PB) {
       if constexpr (part == 0) {
         cv = f32x2_t{R[c][8 * h + 2 * d], R[c][8 * h + 2 * d + 1]};   // (bias: the chain's C operand)
-        if constexpr (!SNR_PAIR_BIAS_C) cv += f32x2_t{biasC[c][0], biasC[c][0]};
       } else {
         unsigned x = __builtin_bit_cast(unsigned, __builtin_convertvector(cv, bf16x2_t));
 #if !(SNR_PAIR_ABLATE & 8)
@@ -630,8 +580,7 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
           Frag& x = rf[arg % WIN];
           if constexpr (!(SNR_PAIR_ABLATE & 16) || o == 0) {
             if constexpr (o == 0 && PB) pair_mfma_reb_first(R[c], x, W[c][0], P[0][1], P[1][1]);
-            else if constexpr (o == 0 && SNR_PAIR_BIAS_C) pair_mfma_reb_first(R[c], x, W[c][0], P[0][1], P[1][1], biasC[c]);
-            else if constexpr (o == 0) pair_mfma_reb_first(R[c], x, W[c][0], P[0][1], P[1][1]);
+            else if constexpr (o == 0) pair_mfma_reb_first(R[c], x, W[c][0], P[0][1], P[1][1], biasC[c]);
             else pair_mfma_reb(R[c], x, W[c][o]);
           }
         } else {
@@ -682,17 +631,12 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
       } else if constexpr (kind == EV_M0) {
         piece_m0(islot, std::integral_constant<int, arg>{});
       } else if constexpr (kind == EV_DMA) {
-        if constexpr (SNR_PAIR_M0_SPLIT) piece_load(std::integral_constant<int, arg>{});
-        else issue_piece(islot, std::integral_constant<int, arg>{});
+        piece_load(std::integral_constant<int, arg>{});
       } else if constexpr (kind == EV_SUM) {
-#if SNR_PAIR_SUM8
         if constexpr (!FIRST) {   // (k-step arg / 4, column block arg % 2, words 2 q, 2 q + 1 with q = arg / 2 % 2)
           const u32x4& w = P[arg % 2][arg / 4];
           pk_sum_bf16_2(bsum[arg % 2], w[2 * (arg / 2 % 2)], w[2 * (arg / 2 % 2) + 1]);
         }
-#else
-        if constexpr (!FIRST) pk_sum_bf16(bsum[arg % 2], P[arg % 2][arg / 2]);   // (k-step arg / 2, column block arg % 2)
-#endif
         __builtin_amdgcn_sched_barrier(0);
       } else if constexpr (kind == EV_SUMA) {
         // kind A, bias gradient of layer 2k+1: the wave sums the rows of its two row tiles (the step's operand registers are
