@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
-B="python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-hashgrid --blocks 3"
+B="python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-hashgrid --no-frame --blocks 3"
 VARS="${VARS:-new wv}"
 for v in $VARS; do
   if [ $v = new ]; then unset SNR_LIB; else export SNR_LIB=$PWD/spin-nerf_amd/lib/ablate/libspinnerf_hip_$v.so; fi
@@ -11,7 +11,7 @@ for i in 1 2 3; do
     timeout 300 $B 2>/dev/null | python -c "
 import sys,json
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); k=d['kernels']
-print('$v', round(d['ms_per_step'],4), 'frame', round(d['ms_per_frame_378x504'],2), 'pair', round(k['mlp_wgrad_pair']['ms_per_step'],4), 'fwd', round(k['mlp_fwd']['ms_per_step'],4), 'dgrad', round(k['mlp_dgrad']['ms_per_step'],4), 'wgrad', round(k['mlp_wgrad']['ms_per_step'],4))
+print('$v', round(d['ms_per_step'],4), 'pair', round(k['mlp_wgrad_pair']['ms_per_step'],4), 'fwd', round(k['mlp_fwd']['ms_per_step'],4), 'dgrad', round(k['mlp_dgrad']['ms_per_step'],4), 'wgrad', round(k['mlp_wgrad']['ms_per_step'],4), 'reduce', round(k['mlp_wgrad_reduce']['ms_per_step'],4))
 " | tee -a gpurun_out/ab_result.txt
   done
 done
