@@ -303,6 +303,24 @@ def test_mlp_backward_bf16(S, vd, wild):
         assert rel < 0.3 and cos > 0.95, f"{k}: vs fp32 autograd: relative L2 error {rel:.2e}, cosine {cos:.4f}"
 
 
+def test_pair_kernel_pacing_does_not_change_the_gradient(S, monkeypatch):
+    """The two kinds of workgroup of the layer-pair weight-gradient kernel pace each other through a progress word
+    (mlp_wgrad_pair.h: kind A looks every SNR_PAIR_POLL tiles and waits while more than SNR_PAIR_LEAD ahead).  Pacing only
+    delays a workgroup: off, default and the tightest setting (look at every tile, never lead) must give bit-identical
+    gradients — and the tightest one must not hang (the wait is bounded)."""
+    grads = []
+    for poll, lead in (("0", "2"), (None, None), ("1", "0")):
+        if poll is None:
+            monkeypatch.delenv("SNR_PAIR_POLL", raising=False); monkeypatch.delenv("SNR_PAIR_LEAD", raising=False)
+        else:
+            monkeypatch.setenv("SNR_PAIR_POLL", poll); monkeypatch.setenv("SNR_PAIR_LEAD", lead)
+        _, net = _mlp_grad_case(S, True, "bf16", 256, 192, seed=11, wild=False, mlp=O.nerf_forward_bf16emu)
+        torch.cuda.synchronize()
+        grads.append(net.flat.grad.detach().clone())
+    assert torch.isfinite(grads[0]).all()
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("vd", [True, False])
 def test_mlp_backward_overwrites_every_element(S, vd, precision):
