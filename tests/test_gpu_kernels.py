@@ -303,6 +303,25 @@ def test_mlp_backward_bf16(S, vd, wild):
         assert rel < 0.3 and cos > 0.95, f"{k}: vs fp32 autograd: relative L2 error {rel:.2e}, cosine {cos:.4f}"
 
 
+@pytest.mark.parametrize("vd", [True, False])
+@pytest.mark.parametrize("n_rays,sps", [(1, 1), (3, 11), (1, 32), (7, 64), (301, 7), (50, 192)])
+def test_mlp_backward_bf16_edge_sizes(S, vd, n_rays, sps):
+    """The recompute path's tile loop at awkward sample counts: one sample, one exact tile, a ragged last tile, fewer
+    tiles than workgroup slots (every slot still owns >= 1 tile or exits), a few hundred tiles.  Same gate as
+    test_mlp_backward_bf16 against the oracle's bf16 emulation; tensors whose reference gradient vanishes must vanish."""
+    sd, net = _mlp_grad_case(S, vd, "bf16", n_rays, sps, seed=21 + n_rays, wild=False, mlp=O.nerf_forward_bf16emu)
+    got = net.named_views(net.flat.grad)
+    assert torch.isfinite(net.flat.grad).all()
+    for k, p in sd.items():
+        if p.grad is None:
+            continue
+        if float(p.grad.abs().max()) == 0.0:
+            assert float(got[k].abs().max()) == 0.0, k
+            continue
+        rel, cos = _rel_l2(got[k], p.grad)
+        assert rel < 5e-2, f"{k}: relative L2 error vs bf16 emulation {rel:.2e} at {n_rays} x {sps}"
+
+
 def test_pair_kernel_pacing_does_not_change_the_gradient(S, monkeypatch):
     """The two kinds of workgroup of the layer-pair weight-gradient kernel pace each other through a progress word
     (mlp_wgrad_pair.h: kind A looks every SNR_PAIR_POLL tiles and waits while more than SNR_PAIR_LEAD ahead).  Pacing only
