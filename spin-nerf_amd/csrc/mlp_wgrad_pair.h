@@ -77,9 +77,6 @@ constexpr int kPairWaves = 4;
 #ifndef SNR_PAIR_SWZ
 #define SNR_PAIR_SWZ 1
 #endif
-#ifndef SNR_PAIR_PREFETCH
-#define SNR_PAIR_PREFETCH 0   // the next body's leading reads are issued by this body's tail as compiler-visible loads
-#endif
 #ifndef SNR_PAIR_ABLATE
 #define SNR_PAIR_ABLATE 0   // timing experiments (results are garbage): 1 no DMA in the tile loop, 2 no LDS waits, 4 no barrier,
 #endif                      // 8 no finishing VALU work (relu / flags), 16 no rebuild MFMAs, 32 no accumulating MFMAs, 64 no operand reads, 128 no row sums
@@ -99,10 +96,11 @@ constexpr int kPairWaves = 4;
 //   middle  all R-steps; in their gaps the DMA pieces of tile i+RING-1, the pointer updates, kind B's column sums.
 //   tail    all A-steps of k-step 1; in their gaps the lower half of the new rebuild is converted into k-step 0's
 //           operand registers (free since the head) — the next body starts on it at once.
-// Every LDS read is issued LA steps ahead of its MFMAs, across the loop's back edge for the head.  Completion is counted:
+// Every LDS read is issued LA steps ahead of its MFMAs — the head's at the top of the body: none is in flight across the loop's
+// back edge (for the compiler an asm read is complete when issued).  Completion is counted:
 // LDS operations retire in order, so the wait in front of an even step (it covers the odd step behind it too) allows
 // exactly the reads issued since (PairProg::young_pair).
-enum { EV_ISSUE = 0, EV_FLAGS, EV_STEP_A, EV_STEP_B, EV_CVT, EV_SYNC, EV_DMA, EV_SUM, EV_SUMA, EV_ADVANCE, EV_PREFETCH, EV_M0 };
+enum { EV_ISSUE = 0, EV_FLAGS, EV_STEP_A, EV_STEP_B, EV_CVT, EV_SYNC, EV_DMA, EV_SUM, EV_SUMA, EV_ADVANCE, EV_M0 };
 template <int TYPE, int KX> struct PairCfg {
   static constexpr bool PB = TYPE == 1;
   static constexpr int KR = PB ? 16 : KX;        // fragments of the rebuild's contraction
@@ -166,13 +164,9 @@ template <int TYPE, int KX> struct PairProg {
     // the first conversion items (they need no LDS data: the wait for the reads falls behind them).  No asm read is ever in
     // flight across the loop's back edge or at its exit: for the compiler such a read is complete when issued, and a copy it
     // places at a loop boundary (or a reuse of the register behind the loop) would meet the old register content.
-    // (SNR_PAIR_PREFETCH: those reads are issued by the previous body's tail instead, as loads the compiler knows — it waits
-    //  for them itself, at the loop head, and never touches a register they are due in)
-    const int n_top = SNR_PAIR_PREFETCH ? 0 : (C::PB ? SNR_PAIR_NTOP_B : SNR_PAIR_NTOP_A);   // conversion micro-items at the top
-    if (!SNR_PAIR_PREFETCH) {
-      if (C::PB) { push(EV_FLAGS, 2, 0); push(EV_FLAGS, 3, 0); }
-      for (int i = 0; i < NS; ++i) if (ip[i] < 0) push(EV_ISSUE, i, 0);
-    }
+    const int n_top = C::PB ? SNR_PAIR_NTOP_B : SNR_PAIR_NTOP_A;   // conversion micro-items at the top
+    if (C::PB) { push(EV_FLAGS, 2, 0); push(EV_FLAGS, 3, 0); }
+    for (int i = 0; i < NS; ++i) if (ip[i] < 0) push(EV_ISSUE, i, 0);
     for (int u = 0; u < n_top; ++u) push(EV_CVT, 16 * 1 + u, 0);
     for (int p = 0; p < NS; ++p) {
       push(EV_STEP_A, p, 0);
@@ -182,7 +176,6 @@ template <int TYPE, int KX> struct PairProg {
           // (... second half — in front of this gap's reads: with WIN = LA + 1 the reads of step p + LA reuse the registers of step p - 1)
           if (p > 0 && order[p - 1] < 0 && !C::PB) push(EV_SUMA, 2 * (p - 1) + 1, 0);
           for (int i = 0; i < NS; ++i) if (ip[i] == p) push(EV_ISSUE, i, 0);
-          if (SNR_PAIR_PREFETCH) for (int i = 0; i < NS; ++i) if (ip[i] < 0 && ip[i] + NS == p) push(EV_PREFETCH, i, 1);
           // M0 of the DMA piece issued behind this step's second MFMA: written a gap ahead, the MFMA in between is the wait
           // state the hardware wants between a scalar write of M0 and the LDS-DMA that reads it
           if (p >= dma_step0 && p < adv_step0) push(EV_M0, p - dma_step0, 0);
@@ -200,11 +193,7 @@ template <int TYPE, int KX> struct PairProg {
         if (g == G - 1 && order[NS - 1] < 0 && !C::PB) push(EV_SUMA, 2 * (NS - 1) + 1, 0);
         for (int u = 0; u < 16; ++u) {
           if (u >= n_top && (u - n_top) * hi_gaps / (16 - n_top) == g && g < hi_gaps) push(EV_CVT, 16 * 1 + u, 0);
-          if (lo_gap0 + u * lo_gaps / 16 == g) {
-            push(EV_CVT, 16 * 0 + u, 0);
-            if (SNR_PAIR_PREFETCH && C::PB && u == 7) push(EV_PREFETCH, NS + 2, 1);    // flag registers of quad 0 / 1 used up:
-            if (SNR_PAIR_PREFETCH && C::PB && u == 15) push(EV_PREFETCH, NS + 3, 1);   // the next tile's k-step-1 flag words
-          }
+          if (lo_gap0 + u * lo_gaps / 16 == g) push(EV_CVT, 16 * 0 + u, 0);
         }
       }
     }
@@ -223,7 +212,7 @@ template <int TYPE, int KX> struct PairProg {
   // e: the EV_STEP_A event of an even step; its wait also covers step + 1 (one s_waitcnt per two steps), whose reads are the younger
   constexpr int young_pair(int e) const {
     const int is = find(EV_ISSUE, arg[e] + 1);
-    return is < 0 ? 15 : between(is, e);   // (prefetched by the previous body as a compiler-visible load: the compiler waits)
+    return is < 0 ? 15 : between(is, e);
   }
   constexpr int young_flags(int t, int e) const {   // e: the event that uses them
     const int is = find(EV_FLAGS, t);
@@ -548,22 +537,6 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
         constexpr int t = arg / 2, quad = arg % 2;
 #pragma unroll
         for (int c = 0; c < 2; ++c) pair_read16u<64 * t + 32 * quad>(fw[c][quad], (nxt ? sN : sA) + fl_addr[c]);
-      } else if constexpr (kind == EV_PREFETCH) {
-        // reads for the NEXT body's head, as loads the compiler tracks (it inserts the wait at their first use and never
-        // copies or reuses their registers early, which it is free to do with an asm read's)
-        typedef short s16x4_t __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4;
-        typedef __attribute__((address_space(3))) u32x4* lds_u32x4;
-        if constexpr (arg < NS) {
-          constexpr int e = ~PG.order[arg], t = e / NM, m = e % NM;
-          tl[arg % WIN] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(aTn + m * 2048 + t * 512)));
-          th[arg % WIN] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(aTn + m * 2048 + t * 512 + 256)));
-        } else {
-          constexpr int quad = arg - NS - 2;
-#pragma unroll
-          for (int c = 0; c < 2; ++c) fw[c][quad] = *(lds_u32x4)(sN + fl_addr[c] + 64 + 32 * quad);
-        }
-        __builtin_amdgcn_sched_barrier(0);
       } else if constexpr (kind == EV_STEP_A || kind == EV_STEP_B) {
         constexpr int o = PG.order[arg];
         constexpr int c = kind == EV_STEP_B ? 1 : 0;   // the column block of this MFMA
