@@ -1,0 +1,8 @@
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+for i in 1 2 3; do
+  python -m pytest tests -m gpu -q --timeout 900 -x -p no:cacheprovider 2>&1 | tail -1 | tee -a gpurun_out/soak.txt
+done
+# the kernel-level bf16 tests 10 more times (intermittent hazards show up as garbage in single tensors)
+for i in $(seq 1 10); do
+  python -m pytest tests/test_gpu_kernels.py -q -x -p no:cacheprovider -k "bf16" 2>&1 | tail -1 | tee -a gpurun_out/soak.txt
+done
