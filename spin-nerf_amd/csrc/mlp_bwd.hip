@@ -178,6 +178,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
       masks_ready(W1{}, mk_next);   // only one block (2 DMA pieces) was issued behind this load so far
     }
     // d z_{i-1} = relu'(h_{i-1}) * (W_i^T d z_i), i = 7..1 ; d z7 is in hB
+#pragma unroll
     for (int it = 0; it < 3; ++it) {
       const int i = 7 - 2 * it;  // consumes d z_i from hB
       roll_masks(W6{});
