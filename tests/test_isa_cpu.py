@@ -69,11 +69,11 @@ def test_built_listings_are_clean():
         # the kernels were recognised (for a round the label pattern missed hipcc's `name: ; @name` lines and the check
         # passed on nothing)
         assert chk.n_kernels[0] - seen >= 5, p
+        txt = open(p).read()
+        assert "ds_read_b128" in txt   # the listing really contains the asm reads
     # no asm global load whose counted wait sits behind a branch (the checker cannot judge those): the kernels are straight-line
     # code between a flag load and its use
     assert chk.unverified[0] == unverified_before, "an asm global load is used behind a branch: not checkable"
-        txt = open(p).read()
-        assert "ds_read_b128" in txt   # the listing really contains the asm reads
 
 
 def test_checker_covers_asm_global_loads(tmp_path):
