@@ -1,0 +1,55 @@
+"""CPU: the committed bench line (profiles/rNN_bench_default.json, a plain `python bench.py` on an MI355X) carries the
+fields the measurement contract names, with consistent arithmetic; and bench.py's model of the workload (MACs per sample
+of the three passes) agrees with the network shapes the oracle defines."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest_line():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))
+    assert files, "no committed bench line"
+    lines = [l for l in open(files[-1]) if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = _latest_line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "training rays/sec" and d["unit"] == "rays/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value is the whole-job rate of the timed region
+    assert abs(d["value"] - d["config"]["global_batch_rays"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # median of the timed blocks
+    assert abs(sorted(d["block_ms"])[len(d["block_ms"]) // 2] / d["steps"] - d["ms_per_step"]) < 1e-6
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    # HBM bytes per launch from the PMC file cannot exceed what 8 TB/s moves in the launch's duration
+    assert r["traffic"] is None or r["traffic"] < 8e12 * r["avg_launch_ms"] * 1e-3
+    assert d["hbm_bytes_per_step"] is None or d["hbm_bytes_per_step"] < 8e12 * d["ms_per_step"] * 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1
+
+
+def test_bench_flop_model_matches_the_network_shapes():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    # forward MACs per sample of the reference network (run_nerf_helpers.py:66-127, viewdirs): 8 trunk layers with the
+    # skip after layer 4, feature + alpha heads, the 283 -> 128 views layer, rgb
+    mac = 63 * 256 + 3 * 256 * 256 + (256 + 63) * 256 + 3 * 256 * 256 + 256 * 256 + 256 * 1 + (256 + 27) * 128 + 128 * 3
+    assert b.MAC_FWD == mac
+    # the layer pairs the recompute kernel handles: layer 0 (63 inputs) and seven 256 x 256 layers
+    assert b.MAC_WGRAD_PAIR == 63 * 256 + 7 * 256 * 256
