@@ -97,6 +97,37 @@ def cpu_baseline(ns, H, W, focal, near, far):
                       f"fp32 torch CPU ops, {threads} threads of a {os.cpu_count()}-thread host, anomaly detection off"}
 
 
+def launch_ranks(n):
+    """Run this script as n ranks of one node through torch.distributed.run (one process per GPU, RCCL), as a CHILD
+    process; returns the exit code.  The parent never initialises the GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in r.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if r.returncode != 0:
+        print(f"bench.py: a rank failed (torch.distributed.run exit code {r.returncode})", file=sys.stderr)
+        return r.returncode or 1
+    if len(lines) != 1:
+        print(f"bench.py: expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    d = json.loads(lines[0])
+    seen = (d.get("distributed") or {}).get("ranks_seen")
+    if d.get("n_gpus") != n or seen != n:
+        print(f"bench.py: --gpus {n} but the run reports n_gpus={d.get('n_gpus')}, ranks_seen={seen}", file=sys.stderr)
+        return 1
+    print(lines[0])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +143,12 @@ def main():
     ap.add_argument("--no-frame", action="store_true")
     ap.add_argument("--no-hashgrid", action="store_true", help="skip the extra measurements (BASELINE config 5 hash-grid networks, config 3 iteration)")
     ns = ap.parse_args()
+
+    if ns.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves — fresh child processes created
+        # BEFORE this process touches the GPU (nothing above initialises HIP; never exec from a process that has) —
+        # relay rank 0's JSON line, and fail loudly unless the collective layer really saw N ranks.
+        sys.exit(launch_ranks(ns.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,8 +170,9 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    if ns.gpus != world and rank == 0:
-        print(f"warning: --gpus {ns.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if ns.gpus != world:
+        # (a scaling run must never silently measure another number of GPUs than it was asked for)
+        raise SystemExit(f"bench.py: --gpus {ns.gpus} but WORLD_SIZE={world}")
 
     import spin_nerf_amd as S
     from importlib import import_module
@@ -170,7 +208,7 @@ def main():
     # sides and reduced with MAX over the ranks; the MEDIAN block is the reported step time (one 20-step block is a 20 ms
     # sample: bimodal at +-2 % and invisible to a 5 s SMI sampler — VERDICT r02), all blocks are listed in `block_ms`
     run_steps(ns.warmup, 0)
-    block_s = []
+    block_s, own_s = [], []
     trainer.comm_reset()
     for b in range(max(1, ns.blocks)):
         sync_all()
@@ -178,6 +216,7 @@ def main():
         run_steps(ns.steps, ns.warmup + b * ns.steps)
         sync_all()
         e = time.perf_counter() - t0
+        own_s.append(e)
         if world > 1:
             import torch.distributed as dist
             t = torch.tensor([e], device=device, dtype=torch.float64)
@@ -186,6 +225,13 @@ def main():
         block_s.append(e)
     elapsed = float(np.median(block_s))
     rays_per_s = world * ns.n_rand * ns.steps / elapsed
+    rank_ms = None                                  # every rank's own median block (the reported time is the MAX per block)
+    if world > 1:
+        import torch.distributed as dist
+        mine = torch.tensor([float(np.median(own_s))], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_ms = [float(t.item()) / ns.steps * 1e3 for t in allr]
     comm_ms = trainer.comm_ms_per_step()          # exposed part of the gradient all-reduce (None on one GPU)
     dist_info = None
     if world > 1:
@@ -195,7 +241,7 @@ def main():
         dist.all_gather(devs, mine)
         dist_info = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
                      "local_device_of_rank": [int(d.item()) for d in devs],
-                     "allreduce_ms_per_step_exposed": comm_ms,
+                     "allreduce_ms_per_step_exposed": comm_ms, "ms_per_step_per_rank": rank_ms,
                      "gradient_bytes_per_step": int(sum(n.flat.numel() for n in trainer.nets) * 4)}
 
     # ---- per-kernel timing with HIP events on the launch stream: the same K steps again, profiled ----

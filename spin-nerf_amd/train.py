@@ -303,8 +303,12 @@ class RenderTrainer:
                 return self._step_direct(H, W, focal, batch_rays, target_s, None)
             try:
                 self._capture(H, W, focal, batch_rays, target_s, key)
-            except Exception:
-                # a failed capture must not be retried on every step: forget the warm-up state and take the eager route
+            except _lib.HipLibraryError:
+                raise                   # a library / launch error is a bug, not a capture limitation: never mask it
+            except RuntimeError as e:   # what torch.cuda.graph raises when something in the step cannot be captured
+                # a failed capture must not be retried on every step: say so, forget the warm-up state, take the eager route
+                import warnings
+                warnings.warn(f"RenderTrainer: HIP-graph capture of the step failed ({e}); continuing on the eager route")
                 self._graph, self._graph_warm, self._graph_on = None, None, False
                 return self._step_direct(H, W, focal, batch_rays, target_s, None)
         G = self._graph

@@ -48,13 +48,13 @@ def import_reference():
     return H, R
 
 
-def npz(name, **arrays):
+def npz(name, out_dir=None, **arrays):
     out = {}
     for k, v in arrays.items():
         if isinstance(v, torch.Tensor):
             v = v.detach().cpu().numpy()
         out[k] = np.asarray(v)
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(out_dir or HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 

@@ -53,3 +53,22 @@ def test_bench_flop_model_matches_the_network_shapes():
     assert b.MAC_FWD == mac
     # the layer pairs the recompute kernel handles: layer 0 (63 inputs) and seven 256 x 256 layers
     assert b.MAC_WGRAD_PAIR == 63 * 256 + 7 * 256 * 256
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks_and_fails_loudly_when_they_fail():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must not quietly measure one GPU: it starts two
+    child ranks through torch.distributed.run.  Here there is no GPU, so both ranks stop with bench.py's "needs an MI355X"
+    and the launcher must relay that as a non-zero exit code and print no JSON line.  (The working path runs on the GPU
+    box: tests/test_gpu_bench_dist.py.)  A --gpus / WORLD_SIZE mismatch is an error as well."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("covered by tests/test_gpu_bench_dist.py on a GPU box")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "a rank failed" in r.stderr
