@@ -13,7 +13,10 @@
  *     contiguous row-major fp32 unless stated; the caller owns all memory (no allocation inside)
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
  *   - return: 0 = ok, <0 = bad argument (SNR_ERR_*), >0 = hipError_t from the launch
- *   - re-entrant per stream; no global state
+ *   - re-entrant per stream.  Process-wide state is limited to: the SNR_* environment switches (A/B experiments) and the
+ *     CU count of each device, read ONCE at the first call that needs them (snr_tunables_reload re-reads the environment);
+ *     the per-kernel LDS attribute set once per device; and the optional profiling log (snr_prof_*).  Nothing a launch
+ *     computes depends on a previous launch.
  */
 #ifndef SPINNERF_HIP_H
 #define SPINNERF_HIP_H
@@ -24,7 +27,8 @@
 extern "C" {
 #endif
 
-#define SNR_ABI_VERSION 2   /* 2: snr_mlp_backward / snr_pack_rays argument lists, snr_net / snr_step_state (round 2) */
+#define SNR_ABI_VERSION 3   /* 2: snr_mlp_backward / snr_pack_rays argument lists, snr_net / snr_step_state (round 2)
+                             * 3: snr_mlp_backward_multi, snr_render_ws_layout.bwd_ws0, snr_tunables_reload (round 4) */
 
 #define SNR_OK 0
 #define SNR_ERR_NULL (-1)         /* a required pointer is NULL */
@@ -85,6 +89,24 @@ int snr_mlp_forward(const snr_mlp_config* cfg, const void* packed, const float* 
 int snr_mlp_backward(const snr_mlp_config* cfg, const void* packed, const float* params, const float* d_raw,
                      int64_t n_samples, const void* act, void* ws, float* grad_params, int accumulate,
                      snr_stream_t stream);
+
+/* The backward passes of SEVERAL networks (the coarse and the fine network of one render_rays, run_nerf.py:593-737, whose
+ * gradients loss.backward() produces together, :1611) as ONE launch sequence: one chain launch, one weight-gradient launch
+ * and one reduce cover all of them — one accumulator flush and one launch ramp instead of one per network.  Every item is
+ * what snr_mlp_backward takes; 1 <= n_items <= 2.  Items that cannot share a launch sequence (fp32 mode, different
+ * use_viewdirs, SNR_RECOMPUTE=0) are run one after the other; the results are the same either way. */
+typedef struct snr_mlp_bwd_item {
+  const snr_mlp_config* cfg;
+  const void* packed;
+  const float* params;
+  const float* d_raw;
+  int64_t n_samples;
+  const void* act;
+  void* ws;               /* snr_mlp_bwd_ws_bytes(cfg, n_samples) of scratch, distinct per item */
+  float* grad_params;
+  int accumulate;
+} snr_mlp_bwd_item;
+int snr_mlp_backward_multi(const snr_mlp_bwd_item* items, int n_items, snr_stream_t stream);
 
 /* ---- hash-grid radiance network: replaces NeRF_TCNN.forward and its autograd (run_nerf_helpers_tcnn.py:13-113; the
  * reference's default network, create_nerf_tcnn, run_nerf.py:499-590).  The reference delegates this arithmetic to
@@ -230,7 +252,9 @@ typedef struct snr_render_config {
 typedef struct snr_render_ws_layout {
   int64_t z_coarse, raw0, weights0, depth0;  /* [n,Nc], [n,Nc,C], [n,Nc], [n] */
   int64_t z_vals, raw, weights, z_samples;   /* [n,Nc+Nf], [n,Nc+Nf,C], [n,Nc+Nf], [n,Nf] (n_importance > 0) */
-  int64_t d_raw0, d_raw, act0, act, bwd_ws;  /* training only */
+  int64_t d_raw0, d_raw, act0, act, bwd_ws;  /* training only; bwd_ws = the final pass's backward scratch */
+  int64_t bwd_ws0;                           /* the coarse pass's backward scratch (n_importance > 0; else bwd_ws serves it):
+                                              * the two backward passes run as one launch sequence and cannot share one */
   int64_t total;                             /* bytes for inference (train == 0) or training */
 } snr_render_ws_layout;
 int snr_render_rays_fused_layout(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine, int64_t n_rays,
@@ -252,7 +276,7 @@ int snr_render_rays_fused_forward(const snr_render_config* cfg, const snr_net* c
 /* parameter gradients of the training forward above (same cfg / networks / rays / ws): grad_coarse and grad_fine (flat
  * fp32) overwritten if accumulate == 0, else += ; fine == NULL: both passes accumulate into grad_coarse.
  * passes: SNR_PASS_FINE | SNR_PASS_COARSE — a data-parallel caller runs the fine pass, starts that network's all-reduce
- * and then runs the coarse pass; the fine pass goes first whenever both are asked for (autograd's order). */
+ * and then runs the coarse pass.  Both passes asked for together run as ONE launch sequence (snr_mlp_backward_multi). */
 #define SNR_PASS_COARSE 1
 #define SNR_PASS_FINE 2
 int snr_render_rays_fused_backward(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine,
@@ -298,6 +322,9 @@ int snr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * snr_prof_read() waits for them, returns total elapsed ms and launch count per kernel id
  * (arrays of snr_prof_kernel_count() entries) and clears the log.  Process-global, off by default. */
 int snr_prof_enable(int on);
+/* re-read the SNR_* environment switches (they are read once, at the first call that needs them): for tests and A/B
+ * scripts that change the environment inside one process.  Not to be called while launches are being enqueued. */
+int snr_tunables_reload(void);
 int snr_prof_kernel_count(void);
 const char* snr_prof_kernel_name(int id);
 int snr_prof_read(double* total_ms, int64_t* launches);

@@ -45,12 +45,17 @@ class RenderConfig(_c.Structure):   # snr_render_config
 
 class RenderWsLayout(_c.Structure):  # snr_render_ws_layout
     _fields_ = [(k, _l) for k in ("z_coarse", "raw0", "weights0", "depth0", "z_vals", "raw", "weights", "z_samples", "d_raw0",
-                                  "d_raw", "act0", "act", "bwd_ws", "total")]
+                                  "d_raw", "act0", "act", "bwd_ws", "bwd_ws0", "total")]
 
 
 class StepState(_c.Structure):      # snr_step_state
     _fields_ = [("offset_base", _c.c_uint64), ("opt_step", _l), ("global_step", _l), ("lr", _f), ("bc1", _f),
                 ("bc2_sqrt", _f), ("reserved", _f)]
+
+
+class MlpBwdItem(_c.Structure):     # snr_mlp_bwd_item
+    _fields_ = [("cfg", _CFG), ("packed", _p), ("params", _p), ("d_raw", _p), ("n_samples", _l), ("act", _p), ("ws", _p),
+                ("grad_params", _p), ("accumulate", _i)]
 
 
 _NET, _RCFG = _c.POINTER(Net), _c.POINTER(RenderConfig)
@@ -66,6 +71,7 @@ SIGNATURES = {
     "snr_mlp_pack": (_i, [_CFG, _p, _p, _p]),
     "snr_mlp_forward": (_i, [_CFG, _p, _p, _p, _i, _p, _p, _i, _l, _i, _p, _p, _p]),
     "snr_mlp_backward": (_i, [_CFG, _p, _p, _p, _l, _p, _p, _p, _i, _p]),
+    "snr_mlp_backward_multi": (_i, [_c.POINTER(MlpBwdItem), _i, _p]),
     "snr_hashgrid_table_entries": (_l, []),
     "snr_hashgrid_param_count": (_l, []),
     "snr_hashgrid_packed_bytes": (_l, []),
@@ -100,6 +106,7 @@ SIGNATURES = {
     "snr_prof_kernel_count": (_i, []),
     "snr_prof_kernel_name": (_c.c_char_p, [_i]),
     "snr_prof_read": (_i, [_c.POINTER(_c.c_double), _c.POINTER(_l)]),
+    "snr_tunables_reload": (_i, []),
 }
 
 _lib = None
@@ -109,7 +116,7 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2   # include/spinnerf_hip.h: SNR_ABI_VERSION (bumped whenever a prototype or a shared struct changes)
+ABI_VERSION = 3   # include/spinnerf_hip.h: SNR_ABI_VERSION (bumped whenever a prototype or a shared struct changes)
 
 
 def load():

@@ -56,7 +56,7 @@ int layout(const snr_render_config* c, const snr_net* nc, const snr_net* nf, int
   const int C0 = out_ch(nc), C1 = out_ch(f);
   int64_t o = 0;
   auto take = [&](int64_t bytes) { const int64_t at = o; o += up(bytes); return at; };
-  *L = snr_render_ws_layout{-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0};
+  *L = snr_render_ws_layout{-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0};
   L->z_coarse = take(n * Nc * 4);
   L->raw0 = take(n * Nc * C0 * 4);
   L->weights0 = take(n * Nc * 4);
@@ -80,7 +80,8 @@ int layout(const snr_render_config* c, const snr_net* nc, const snr_net* nf, int
       L->act = take(a1);
       if (b1 > bw) bw = b1;
     }
-    L->bwd_ws = take(bw);   // the two backward passes run one after the other on the stream and share it
+    L->bwd_ws = take(bw);   // the final pass's (or the only pass's) backward scratch
+    if (Nf > 0) L->bwd_ws0 = take(b0);   // the coarse pass's own: both backward passes run as one launch sequence
   }
   L->total = o;
   return SNR_OK;
@@ -166,6 +167,14 @@ extern "C" int snr_render_rays_fused_backward(const snr_render_config* cfg, cons
   if (coarse->kind == SNR_NET_MLP && coarse->mlp.use_viewdirs && !coarse->params) return SNR_ERR_NULL;
   char* w = (char*)ws;
   auto F = [&](int64_t off) { return (float*)(w + off); };
+  char* ws0 = w + (Nf > 0 ? L.bwd_ws0 : L.bwd_ws);   // the coarse pass's backward scratch
+  if (do_fine && do_coarse && fine && coarse->kind == SNR_NET_MLP && fine->kind == SNR_NET_MLP) {
+    // both MLP backward passes as one launch sequence
+    const snr_mlp_bwd_item items[2] = {
+        {&fine->mlp, fine->packed, fine->params, F(L.d_raw), n_rays * S, w + L.act, w + L.bwd_ws, grad_fine, accumulate},
+        {&coarse->mlp, coarse->packed, coarse->params, F(L.d_raw0), n_rays * Nc, w + L.act0, ws0, grad_coarse, accumulate}};
+    return snr_mlp_backward_multi(items, 2, stream);
+  }
   int acc_c = accumulate;
   if (do_fine) {   // the fine pass first: autograd's order, and (data-parallel) its all-reduce can start under the coarse pass
     const snr_net* f = fine ? fine : coarse;
@@ -175,6 +184,6 @@ extern "C" int snr_render_rays_fused_backward(const snr_render_config* cfg, cons
     if (!fine) acc_c = 1;
   }
   if (!do_coarse) return SNR_OK;
-  return net_backward(coarse, rays, ray_ld, F(L.z_coarse), n_rays, Nc, F(L.d_raw0), w + L.act0, w + L.bwd_ws, grad_coarse, acc_c,
+  return net_backward(coarse, rays, ray_ld, F(L.z_coarse), n_rays, Nc, F(L.d_raw0), w + L.act0, ws0, grad_coarse, acc_c,
                       stream);
 }

@@ -533,15 +533,7 @@ static WgradArgs hg_make_jobs(int64_t n_samples, int64_t net_off, int64_t* part_
   out(job(HgWs::K_DHC2, 4, HgWs::K_HC1, 4), 64, SRC_H, 64, SRC_H, w2c, 64, 64, 64);
   out(job(HgWs::K_DRGB, 1, HgWs::K_HC2, 4), 16, SRC_OUT, 64, SRC_H, w3c, 64, 16, 64);
   A.n_jobs = n; A.n_outs = no;
-  int target = 256;
-  {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-      target = cus;
-    else
-      (void)hipGetLastError();
-  }
+  const int target = cu_count();
   int64_t cost = 0;
   for (int i = 0; i < n; ++i) cost += A.job[i].a_ks + A.job[i].b_ks;
   int sb = 0;

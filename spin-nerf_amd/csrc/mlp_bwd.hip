@@ -40,10 +40,17 @@ struct DgradArgs {
   const char* act;        // forward workspace (masks)
   char* ws;               // d z sections
   int save_even;          // 0: d z0, d z2, d z4, d z6 are not saved (rebuilt by the weight-gradient pass)
+  unsigned* zero_words;   // progress words of the layer-pair launch that follows (mlp_wgrad_pair.h), cleared here; or null
+  int n_zero;
+  int block0, blocks;     // this network's workgroups of the launch: [block0, block0 + blocks), grid-striding over its tiles
 };
+// (round 4) one launch runs the chains of up to two networks (coarse + fine backward): a workgroup belongs to one network
+// for its whole life (its weight stream is that network's)
+struct DgradMulti { int n; DgradArgs net[kMaxReduceNets]; };
 
 template <int P, bool VD>
-__global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_kernel(DgradArgs a) {
+__global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_kernel(DgradMulti mm) {
+  const DgradArgs& a = mm.net[(mm.n > 1 && (int)blockIdx.x >= mm.net[1].block0) ? 1 : 0];
   using B = Blob<P>;
   using M = Mma<P>;
   using Frag = typename M::Frag;
@@ -69,7 +76,8 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
   using IH = std::integral_constant<int, KS_H>;
   using IH9 = std::integral_constant<int, KS_H9>;
 
-  for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
+  if ((int)blockIdx.x == a.block0 && a.zero_words && tid < a.n_zero) a.zero_words[tid] = 0u;
+  for (int64_t wg = (int)blockIdx.x - a.block0; wg < n_wg; wg += a.blocks) {
     const int64_t tile0 = (wg * WAVES + wave) * NJ;
 
     // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section for every sample tile of this wave
@@ -214,8 +222,8 @@ int snr::wgrad_launch_bf16(const WgradArgs& w, int total_splits, float* grad, in
   {
     ProfScope ps(K_MLP_WGRAD_REDUCE, s);
     ReduceArgs ra{};
-    append_reduce(ra, w);
-    mlp_wgrad_reduce_kernel<kBF16><<<dim3((per_out + 255) / 256, (unsigned)ra.n_outs), dim3(256), 0, s>>>(ra, grad, accumulate);
+    if (!append_reduce(ra, w, 0, grad, accumulate)) return SNR_ERR_UNSUPPORTED;
+    mlp_wgrad_reduce_kernel<kBF16><<<dim3((per_out + 255) / 256, (unsigned)ra.n_outs), dim3(256), 0, s>>>(ra);
   }
   return launch_status();
 }
@@ -235,10 +243,14 @@ static int check_cfg_b(const snr_mlp_config* c) {
 }
 
 template <int P> static int64_t ws_bytes(const snr_mlp_config* c, int64_t n) {
-  int64_t pf; int ts;
   const bool rc = P == kBF16 && recompute_enabled();
-  make_jobs<P>(c, n, &pf, &ts, rc);
-  if (rc) pf += make_pair_plan(c, n, pf).part_floats;
+  int64_t pf;
+  if (rc) {
+    pf = wgall_part_bound();   // whatever launch the network takes part in (alone, or merged with another network's backward)
+  } else {
+    int ts;
+    make_jobs<P>(c, n, &pf, &ts, false);
+  }
   return WsLayout<P>(n, c->use_viewdirs).dz_bytes() + (pf + kPostFloats) * 4;
 }
 
@@ -249,66 +261,82 @@ extern "C" int64_t snr_mlp_bwd_ws_bytes(const snr_mlp_config* c, int64_t n) {
   return c->precision == SNR_PREC_BF16 ? ws_bytes<kBF16>(c, n) : ws_bytes<kFP32>(c, n);
 }
 
+// one network's backward problem (include/spinnerf_hip.h: snr_mlp_bwd_item)
+typedef snr_mlp_bwd_item BwdItem;
+
+template <int P> static DgradArgs dgrad_args(const BwdItem& it, bool save_even) {
+  const snr_mlp_config* c = it.cfg;
+  const PackTable T = make_pack_table<P>(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
+  DgradArgs d{};
+  d.blob_bwd = (const char*)it.packed + (int64_t)T.fwd_frags * 1024;
+  d.bwd_blocks = T.bwd_frags / kBlockFrags;
+  d.d_raw = it.d_raw; d.n_samples = it.n_samples; d.out_ch = c->out_ch;
+  d.act = (const char*)it.act; d.ws = (char*)it.ws;
+  d.save_even = save_even;
+  return d;
+}
+
+// the chains of 1..2 networks in one launch; the workgroups are shared out in proportion to the networks' tiles
 template <int P, bool VD>
-static int launch_dgrad(const DgradArgs& a, hipStream_t s) {
-  const int64_t n_wg = padded_tiles<P>(a.n_samples) / (ChainCfg<P, true>::WAVES * ChainCfg<P, true>::NJ);
+static int launch_dgrad(DgradMulti& m, hipStream_t s) {
+  constexpr int per_wg = ChainCfg<P, true>::WAVES * ChainCfg<P, true>::NJ;
+  int64_t n_wg[kMaxReduceNets], total = 0;
+  for (int i = 0; i < m.n; ++i) { n_wg[i] = padded_tiles<P>(m.net[i].n_samples) / per_wg; total += n_wg[i]; }
+  const int64_t budget = 1024;   // one workgroup per CU is resident; the rest grid-stride
+  int block = 0;
+  for (int i = 0; i < m.n; ++i) {
+    int64_t g = total <= budget ? n_wg[i] : n_wg[i] * budget / total;
+    if (g < 1) g = 1;
+    m.net[i].block0 = block; m.net[i].blocks = (int)g; block += (int)g;
+  }
   const int lds = kRingBytes;
   if (int e = ensure_dynamic_lds<&mlp_dgrad_kernel<P, VD>>(lds)) return e;
-  const int64_t grid = n_wg < 1024 ? n_wg : 1024;
   {
     ProfScope ps(K_MLP_DGRAD, s);
-    mlp_dgrad_kernel<P, VD><<<dim3((unsigned)grid), dim3(64 * ChainCfg<P, true>::WAVES), lds, s>>>(a);
+    mlp_dgrad_kernel<P, VD><<<dim3((unsigned)block), dim3(64 * ChainCfg<P, true>::WAVES), lds, s>>>(m);
   }
   return launch_status();
 }
 
-template <int P>
-static int backward_impl(const snr_mlp_config* c, const void* packed, const float* params, const float* d_raw, int64_t n,
-                         const void* act, void* ws, float* grad, int accumulate, hipStream_t s) {
-  const PackTable T = make_pack_table<P>(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
+// The reduce kernel stores every parameter a weight-gradient job produces; the only parameters no job
+// produces are views_linears.0 of a network without view directions (unused, but part of the state dict).
+static int clear_unused_grads(const BwdItem& it, hipStream_t s) {
+  const snr_mlp_config* c = it.cfg;
+  if (it.accumulate || c->use_viewdirs) return SNR_OK;
   const ParamLayout L = make_param_layout(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
-  // The reduce kernel stores every parameter a weight-gradient job produces; the only parameters no job
-  // produces are views_linears.0 of a network without view directions (unused, but part of the state dict).
-  if (!accumulate && !c->use_viewdirs) {
-    hipError_t e = hipMemsetAsync(grad + L.w_views, 0, (size_t)((L.b_views + kW / 2) - L.w_views) * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
-  }
-  DgradArgs d{};
-  d.blob_bwd = (const char*)packed + (int64_t)T.fwd_frags * 1024;
-  d.bwd_blocks = T.bwd_frags / kBlockFrags;
-  d.d_raw = d_raw; d.n_samples = n; d.out_ch = c->out_ch;
-  d.act = (const char*)act; d.ws = (char*)ws;
-  const bool rc = P == kBF16 && recompute_enabled();
-  d.save_even = !rc;
-  int st = c->use_viewdirs ? launch_dgrad<P, true>(d, s) : launch_dgrad<P, false>(d, s);
-  if (st != SNR_OK) return st;
+  hipError_t e = hipMemsetAsync(it.grad_params + L.w_views, 0, (size_t)((L.b_views + kW / 2) - L.w_views) * sizeof(float), s);
+  return e == hipSuccess ? SNR_OK : (int)e;
+}
 
+static PostNet post_net(const BwdItem& it, const float* post) {
+  const snr_mlp_config* c = it.cfg;
+  const ParamLayout L = make_param_layout(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
+  PostNet pn{};
+  pn.params = it.params; pn.post = post; pn.grad = it.grad_params;
+  pn.w_views = (int)L.w_views; pn.ld_views = kW + L.in_dir; pn.w_feat = (int)L.w_feat; pn.b_feat = (int)L.b_feat;
+  pn.accumulate = it.accumulate;
+  return pn;
+}
+
+constexpr int kReducePerOut = 4 * 256 * (256 / 4 + 1);   // 4 lanes per item; items = rows x (4-column groups + the bias)
+
+// ---- one network, every layer saved: the plain split-K pass (fp32 mode; bf16 with SNR_RECOMPUTE=0) ----
+template <int P>
+static int backward_plain(const BwdItem& it, hipStream_t s) {
+  const snr_mlp_config* c = it.cfg;
+  int st = clear_unused_grads(it, s);
+  if (st != SNR_OK) return st;
+  DgradMulti m{};
+  m.n = 1;
+  m.net[0] = dgrad_args<P>(it, true);
+  st = c->use_viewdirs ? launch_dgrad<P, true>(m, s) : launch_dgrad<P, false>(m, s);
+  if (st != SNR_OK) return st;
   int64_t pf; int total_splits;
-  WgradArgs w = make_jobs<P>(c, n, &pf, &total_splits, rc);
-  w.act = (const char*)act;
-  w.ws = (const char*)ws;
-  w.part = (float*)((char*)ws + WsLayout<P>(n, c->use_viewdirs).dz_bytes());
-  PairPlan pp{};
-  if constexpr (P == kBF16) {
-    if (rc) {
-      // the trunk layers: layer-pair kernel with selective recompute (mlp_wgrad_pair.h), its partial planes behind the plain pass's
-      pp = make_pair_plan(c, n, pf);
-      pp.pa.act = w.act; pp.pa.ws = w.ws; pp.pa.part = w.part;
-      pp.pa.blob = (const char*)packed;
-      pp.pa.bias = (const float*)((const char*)packed + (int64_t)(T.fwd_frags + T.bwd_frags) * 1024);
-      pp.red.act = w.act; pp.red.ws = w.ws; pp.red.part = w.part;
-      pf += pp.part_floats;
-      if (int e = ensure_dynamic_lds<&mlp_wgrad_pair_kernel>(kLdsBytes)) return e;
-      {
-        ProfScope ps(K_MLP_WGRAD_PAIR, s);
-        mlp_wgrad_pair_kernel<<<dim3((unsigned)pp.grid), dim3(64 * kPairWaves), kLdsBytes, s>>>(pp.pa);
-      }
-      st = launch_status();
-      if (st != SNR_OK) return st;
-    }
-  }
+  WgradArgs w = make_jobs<P>(c, it.n_samples, &pf, &total_splits, false);
+  w.act = (const char*)it.act;
+  w.ws = (const char*)it.ws;
+  w.part = (float*)((char*)it.ws + WsLayout<P>(it.n_samples, c->use_viewdirs).dz_bytes());
   w.post = w.part + pf;
-  pp.red.post = w.post;
   constexpr int lds = WgradCfg<P>::RING * 2 * Blob<P>::KS_H * 1024;   // the largest ring of any job (mlp_wgrad.h)
   if (int e = ensure_dynamic_lds<&mlp_wgrad_kernel<P>>(lds)) return e;
   {
@@ -317,33 +345,117 @@ static int backward_impl(const snr_mlp_config* c, const void* packed, const floa
   }
   st = launch_status();
   if (st != SNR_OK) return st;
-  const int per_out = 4 * 256 * (256 / 4 + 1);   // 4 lanes per item; items = rows x (4-column groups + the bias)
   {
     ProfScope ps(K_MLP_WGRAD_REDUCE, s);
     ReduceArgs ra{};
-    append_reduce(ra, w);
-    if (rc) append_reduce(ra, pp.red);   // (same partial-sum buffer and G block)
-    mlp_wgrad_reduce_kernel<P><<<dim3((per_out + 255) / 256, (unsigned)ra.n_outs), dim3(256), 0, s>>>(ra, grad, accumulate);
+    if (!append_reduce(ra, w, 0, it.grad_params, it.accumulate)) return SNR_ERR_UNSUPPORTED;
+    mlp_wgrad_reduce_kernel<P><<<dim3((kReducePerOut + 255) / 256, (unsigned)ra.n_outs), dim3(256), 0, s>>>(ra);
     if (c->use_viewdirs) {
       PostArgs pa{};
-      pa.params = params; pa.post = w.post; pa.grad = grad;
-      pa.w_views = (int)L.w_views; pa.ld_views = kW + L.in_dir; pa.w_feat = (int)L.w_feat; pa.b_feat = (int)L.b_feat;
-      pa.accumulate = accumulate;
-      wgrad_post_kernel<P><<<dim3(104), dim3(256), 0, s>>>(pa);
+      pa.net[0] = post_net(it, w.post);
+      wgrad_post_kernel<P><<<dim3(kPostTiles), dim3(256), 0, s>>>(pa);
     }
   }
   return launch_status();
 }
 
+// ---- bf16 with selective recompute: ONE launch sequence for the backward passes of 1..2 networks ----
+//   dgrad chains of every network | layer pairs + plain jobs of every network | reduce of every partial plane | the G products
+static int backward_merged(const BwdItem* items, int n, hipStream_t s) {
+  constexpr int P = kBF16;
+  const bool vd = items[0].cfg->use_viewdirs;
+  WgNet nets[kMaxReduceNets];
+  for (int i = 0; i < n; ++i) {
+    int st = clear_unused_grads(items[i], s);
+    if (st != SNR_OK) return st;
+    nets[i] = WgNet{};
+    nets[i].c = items[i].cfg; nets[i].n_samples = items[i].n_samples;
+  }
+  WgAllPlan pl;
+  int st = make_wgall_plan(nets, n, pl);
+  if (st != SNR_OK) return st;
+  DgradMulti m{};
+  m.n = n;
+  ReduceArgs ra{};
+  PostArgs post{};
+  for (int i = 0; i < n; ++i) {
+    const BwdItem& it = items[i];
+    const snr_mlp_config* c = it.cfg;
+    const PackTable T = make_pack_table<P>(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
+    float* part = (float*)((char*)it.ws + WsLayout<P>(it.n_samples, c->use_viewdirs).dz_bytes());
+    float* g_block = part + nets[i].part_floats;     // G (+ s9) behind this launch's partial sums
+    m.net[i] = dgrad_args<P>(it, false);
+    m.net[i].zero_words = (unsigned*)(part + nets[i].sync_off);
+    m.net[i].n_zero = kSyncWords;
+    fill_wgall_pointers(pl, nets, i, (const char*)it.act, (const char*)it.ws, (const char*)it.packed,
+                        (const float*)((const char*)it.packed + (int64_t)(T.fwd_frags + T.bwd_frags) * 1024), part);
+    nets[i].plain.part = part; nets[i].plain.post = g_block;
+    nets[i].red.part = part; nets[i].red.post = g_block;
+    if (!append_reduce(ra, nets[i].plain, i, it.grad_params, it.accumulate)) return SNR_ERR_UNSUPPORTED;
+    if (!append_reduce(ra, nets[i].red, i, it.grad_params, it.accumulate)) return SNR_ERR_UNSUPPORTED;
+    post.net[i] = post_net(it, g_block);
+  }
+  st = vd ? launch_dgrad<P, true>(m, s) : launch_dgrad<P, false>(m, s);
+  if (st != SNR_OK) return st;
+  if (int e = ensure_dynamic_lds<&mlp_wgrad_pair_kernel>(kLdsBytes)) return e;
+  {
+    ProfScope ps(K_MLP_WGRAD_PAIR, s);
+    mlp_wgrad_pair_kernel<<<dim3((unsigned)pl.grid), dim3(64 * kPairWaves), kLdsBytes, s>>>(pl.pa);
+  }
+  st = launch_status();
+  if (st != SNR_OK) return st;
+  {
+    ProfScope ps(K_MLP_WGRAD_REDUCE, s);
+    mlp_wgrad_reduce_kernel<P><<<dim3((kReducePerOut + 255) / 256, (unsigned)ra.n_outs), dim3(256), 0, s>>>(ra);
+    if (vd) wgrad_post_kernel<P><<<dim3((unsigned)(kPostTiles * n)), dim3(256), 0, s>>>(post);
+  }
+  return launch_status();
+}
+
+static int check_item(const BwdItem& it) {
+  int st = check_cfg_b(it.cfg);
+  if (st != SNR_OK) return st;
+  SNR_CHECK_ARG(it.packed && it.d_raw && it.act && it.ws && it.grad_params && (it.params || !it.cfg->use_viewdirs), SNR_ERR_NULL);
+  SNR_CHECK_ARG(it.n_samples > 0, SNR_ERR_SHAPE);
+  return SNR_OK;
+}
+
+extern "C" int snr_mlp_backward_multi(const snr_mlp_bwd_item* items, int n_items, snr_stream_t stream) {
+  SNR_CHECK_ARG(items, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_items >= 1 && n_items <= kMaxReduceNets, SNR_ERR_SHAPE);
+  for (int i = 0; i < n_items; ++i) {
+    int st = check_item(items[i]);
+    if (st != SNR_OK) return st;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // one launch sequence for all of them: bf16 networks with selective recompute that share the kernels' compile-time shape
+  // (view directions or not) and are distinct problems (a buffer cannot be two networks' workspace at once)
+  bool merged = recompute_enabled();
+  for (int i = 0; i < n_items; ++i) {
+    merged = merged && items[i].cfg->precision == SNR_PREC_BF16 && items[i].cfg->use_viewdirs == items[0].cfg->use_viewdirs;
+    if (i > 0) merged = merged && tunables().merge_nets && items[i].ws != items[0].ws && items[i].act != items[0].act &&
+                        items[i].grad_params != items[0].grad_params;
+  }
+  if (merged) return backward_merged(items, n_items, s);
+  for (int i = 0; i < n_items; ++i) {
+    const BwdItem& it = items[i];
+    int st;
+    if (it.cfg->precision == SNR_PREC_BF16) st = recompute_enabled() ? backward_merged(&it, 1, s) : backward_plain<kBF16>(it, s);
+    else st = backward_plain<kFP32>(it, s);
+    if (st != SNR_OK) return st;
+  }
+  return SNR_OK;
+}
+
 extern "C" int snr_mlp_backward(const snr_mlp_config* c, const void* packed, const float* params, const float* d_raw,
                                 int64_t n, const void* act, void* ws, float* grad, int accumulate, snr_stream_t stream) {
-  int st = check_cfg_b(c);
-  if (st != SNR_OK) return st;
-  SNR_CHECK_ARG(packed && d_raw && act && ws && grad && (params || !c->use_viewdirs), SNR_ERR_NULL);
-  SNR_CHECK_ARG(n > 0, SNR_ERR_SHAPE);
-  hipStream_t s = (hipStream_t)stream;
-  return c->precision == SNR_PREC_BF16 ? backward_impl<kBF16>(c, packed, params, d_raw, n, act, ws, grad, accumulate, s)
-                                       : backward_impl<kFP32>(c, packed, params, d_raw, n, act, ws, grad, accumulate, s);
+  const snr_mlp_bwd_item it{c, packed, params, d_raw, n, act, ws, grad, accumulate};
+  return snr_mlp_backward_multi(&it, 1, stream);
+}
+
+extern "C" int snr_tunables_reload(void) {
+  tunables_storage() = read_tunables();
+  return SNR_OK;
 }
 
 #ifdef SNR_TIMING

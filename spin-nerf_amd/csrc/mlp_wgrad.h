@@ -61,7 +61,6 @@ struct WgradOut {
   int cols_valid;               // valid true columns of the B side
   int bias_off;                 // destination bias or -1
   int to_scratch;               // 1: destination offsets are relative to the G block (stored, never accumulated)
-  int transposed;               // 1: the A side indexes weight COLUMNS and the B side weight ROWS (mlp_wgrad_pair.h, kind A)
 };
 constexpr int kMaxJobs = 12, kMaxOuts = 20;
 struct WgradArgs {
@@ -415,6 +414,300 @@ __global__ __launch_bounds__(64 * kWgradWaves) void mlp_wgrad_kernel(WgradArgs a
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 4: the same split-K job as a FOUR-wave workgroup with up to 512 registers per lane — the shape of the layer-pair
+// kernel (mlp_wgrad_pair.h), in whose launch the plain jobs now run on a few dedicated CUs: these jobs are bound by their
+// DMA stream (a CU pulls ~33 GB/s through LDS-DMA whatever else the chip does: tests/probes/r04_cu_split.sh), the pair
+// workgroups by the matrix pipe, so ~40 CUs stream the plain jobs' 0.46 GB while the other ~216 compute — instead of
+// 256 CUs doing first one, then the other.
+// With one wave per SIMD nothing hides a wave's stalls, so the waves specialise (first cut: all four issued DMA and
+// computed, 1.85x the CU time of the 8-wave kernel — the DMA issue stalls and the LDS latency sat on the MFMA waves'
+// critical path, and 5 x 9 tiles do not divide by four):
+//   wave 3      LOADER: issues every DMA piece of a tile, waits for the oldest tile in flight, joins the barrier
+//   waves 0..2  CONSUMERS: a third of the job's output tiles each — by rows (rows_mode: d z5 x pe, 8 x 2 tiles -> 3 + 3 + 2
+//               row tiles) or by columns (5 x 9 -> 3 column tiles x 5 rows each) —; all transposing reads of a tile are
+//               issued at once (both k-steps), then the MFMAs run back to back behind counted waits
+// One barrier per tile: behind it tile t has landed (the loader waited) and everybody is done with tile t - 1, whose slot
+// the loader refills.  Reads, MFMA operand order, partial-plane layout: exactly wgrad_run's.
+// ------------------------------------------------------------------------------------------
+constexpr int kPlainWaves = 4, kPlainConsumers = 3;
+SNR_HD int plain_third(int w, int n) { return (w * n + 2) / 3; }   // first tile of consumer w of n tiles: sizes differ by <= 1
+
+// Y = tiles in flight behind the one being waited for (ring = Y + 2 slots).  Every wave issues DMA pieces — a wave's counted
+// wait needs an immediate and vmcnt has 6 bits, so ONE wave cannot keep more than 63 KiB in flight, too little to cover the
+// HBM latency at 33 GB/s —: the loader the first PL pieces of a tile, consumer w the pieces PL + w + 3 k, k < PC (clamped to
+// the tile's last piece: every wave issues a fixed count), each at the top of its tile-loop body, where nothing of its own is
+// waiting on the issue queue.  Y * PL and Y * PC <= 63.
+template <int NR, int NC, int Y, int PL, int PC>
+__device__ __forceinline__ void plain_run4(const WgradLocal& L, char* smem, int wave, int lane, int cols_mode, int nta, int ntb) {
+  using M = Mma<kBF16>;
+  using Frag = typename M::Frag;
+  constexpr int R = Y + 2;
+  static_assert(Y * PL <= 63 && Y * PC <= 63, "the counted waits need immediates below 64");
+  const int a_ks = L.a_ks, b_ks = L.b_ks;
+  const int per_tile = a_ks + b_ks;
+  const int SLOT = per_tile * 1024;
+
+  // where piece p of a tile comes from: (A sections first, then B sections)
+  const char *a0b = L.a0_base, *a1b = L.a1_base, *b0b = L.b0_base, *b1b = L.b1_base;
+  int a0k = L.a0_ks, a1k = L.a1_ks, b0k = L.b0_ks, b1k = L.b1_ks;
+  asm volatile("" : "+s"(a0b), "+s"(a1b), "+s"(b0b), "+s"(b1b), "+s"(a0k), "+s"(a1k), "+s"(b0k), "+s"(b1k));
+  // (computed in place, element by element with compile-time indices, like wgrad_run: handing an array element to a helper
+  //  by reference leaves the arrays in scratch memory, and every scratch load is a vector-memory load that the compiler
+  //  waits for with vmcnt(0) — it would drain the DMA queue)
+#define SNR_PIECE_SRC(P_EXPR, SRC, STRIDE)                                          \
+  do {                                                                              \
+    const int p_ = (P_EXPR);                                                        \
+    const bool isA_ = p_ < a_ks;                                                    \
+    int q_ = isA_ ? p_ : p_ - a_ks;                                                 \
+    const int ks0_ = isA_ ? a0k : b0k;                                              \
+    const bool second_ = q_ >= ks0_;                                                \
+    if (second_) q_ -= ks0_;                                                        \
+    const char* base_ = isA_ ? (second_ ? a1b : a0b) : (second_ ? b1b : b0b);       \
+    const int ks_ = isA_ ? (second_ ? a1k : a0k) : (second_ ? b1k : b0k);           \
+    (SRC) = base_ + (L.t0 * ks_ + q_) * 1024 + lane * 16;                           \
+    (STRIDE) = ks_ * 1024 * L.tstep;                                                \
+  } while (0)
+
+  if (wave == kPlainConsumers) {
+    // ---------------- loader: pieces 0 .. PL-1 of every tile ----------------
+    const char* src[PL];
+    int stride[PL];
+#pragma unroll
+    for (int k = 0; k < PL; ++k) SNR_PIECE_SRC(k < per_tile ? k : per_tile - 1, src[k], stride[k]);
+    int64_t issued = 0;
+    auto issue_tile = [&](int slot) {
+      static_for<0, PL>([&](auto K_) {
+        constexpr int k = decltype(K_)::value;
+        __builtin_amdgcn_global_load_lds(src[k], SNR_LDS(smem + slot * SLOT + (k < per_tile ? k : per_tile - 1) * 1024), 16, 0, 0);
+      });
+      if (issued + 1 < L.t1) {   // past the end the last tile is loaded again: uniform counts
+        ++issued;
+#pragma unroll
+        for (int k = 0; k < PL; ++k) src[k] += stride[k];
+      }
+    };
+    for (int d = 0; d <= Y; ++d) issue_tile(d % R);
+    int islot = (Y + 1) % R;
+    for (int64_t tile = 0; tile < L.t1; ++tile) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y * PL) : "memory");   // this wave's pieces of `tile` have landed (loads retire in order)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_tile(islot);
+      islot = islot + 1 == R ? 0 : islot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing re-loads
+    return;
+  }
+
+  // ---------------- consumers: pieces PL + wave + 3 k ----------------
+  const char* src[PC];
+  int stride[PC], lds_off[PC];
+#pragma unroll
+  for (int k = 0; k < PC; ++k) {
+    int p = PL + wave + kPlainConsumers * k;
+    if (p >= per_tile) p = per_tile - 1;
+    SNR_PIECE_SRC(p, src[k], stride[k]);
+    lds_off[k] = p * 1024;
+  }
+  int64_t issued = 0;
+  auto issue_mine = [&](int slot) {
+    static_for<0, PC>([&](auto K_) {
+      constexpr int k = decltype(K_)::value;
+      asm volatile("s_nop 0");   // no LDS read in the cycle in front of an LDS-DMA (mlp_device.h, Pipe::issue_one)
+      __builtin_amdgcn_global_load_lds(src[k], SNR_LDS(smem + slot * SLOT + lds_off[k]), 16, 0, 0);
+    });
+    if (issued + 1 < L.t1) {
+      ++issued;
+#pragma unroll
+      for (int k = 0; k < PC; ++k) src[k] += stride[k];
+    }
+  };
+  for (int d = 0; d <= Y; ++d) issue_mine(d % R);
+  int islot = (Y + 1) % R;
+#undef SNR_PIECE_SRC
+
+  // ---------------- consumers ----------------
+  // this wave's tiles (wave-uniform): row tiles r0 .. r0 + nr, column tiles c0 .. c0 + nc
+  const int r0 = cols_mode ? 0 : plain_third(wave, nta), nr = (cols_mode ? nta : plain_third(wave + 1, nta)) - r0;
+  const int c0 = cols_mode ? plain_third(wave, ntb) : 0, nc = (cols_mode ? plain_third(wave + 1, ntb) : ntb) - c0;
+  const bool do_bias = !cols_mode || wave == 0;   // by columns every consumer holds every row: wave 0 sums them
+
+  f32x16 acc[NR][NC];
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) bsum[i] = 0.f;
+
+  // tile-invariant LDS offsets of the transposing reads (wgrad_run); rows / columns this wave does not have re-read its first
+  const int G = lane >> 4, ip = lane & 15, gg = G >> 1, bh = G & 1, c4 = ip & 3, r4 = ip >> 2;
+  int offA[NR][2], offB[NC][2];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int rt = i < nr ? r0 + i : r0;
+    const int bhA = (2 * rt + 1 < a_ks) ? bh : 0;   // a 16-wide OUT section closes the A side with a single block
+#pragma unroll
+    for (int q = 0; q < 2; ++q) offA[i][q] = (2 * rt + bhA) * 1024 + (8 * gg + ((4 * q) ^ (4 * bhA)) + r4) * 32 + c4 * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int ct = j < nc ? c0 + j : c0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) offB[j][q] = a_ks * 1024 + (2 * ct + bh) * 1024 + (8 * gg + ((4 * q) ^ (4 * bh)) + r4) * 32 + c4 * 8;
+  }
+  const int i32 = lane & 31, g32 = lane >> 5;
+
+  // Software pipeline over the k-steps (16 samples each, two per tile): while the MFMAs of one k-step run out of one operand
+  // register set, the transposing reads of the NEXT k-step go to the other set, one or two behind every MFMA (an LDS read or
+  // a DMA piece issued behind an MFMA runs in its shadow; issued in a block in front of the MFMAs — the first cut — they were
+  // the workgroup's critical path: 18.8 CU-ms for the step's plain jobs against 14 of the 8-wave kernel).  A tile's body:
+  //   MFMAs (k, step 0) from set 0 | reads (k, step 1) -> set 1 ; barrier k + 1 ; MFMAs (k, step 1) from set 1 | reads (k + 1, step 0) -> set 0
+  // At the barrier this wave has READ all of tile k (its slot is refilled behind the barrier) and its own pieces of tile
+  // k + 1 have landed; behind it tile k + 1 is complete for everybody.
+  constexpr int NRDH = 2 * (NR + NC), NMMH = NR * NC;   // reads, MFMAs per k-step
+  constexpr int NLEAD = NMMH > 6 ? NMMH - 4 : (NMMH > 1 ? NMMH / 2 : 1);   // the reads go out behind the first NLEAD MFMAs
+  bf16x4 alo[2][NR], ahi[2][NR], blo[2][NC], bhi[2][NC];   // [register set = k-step][tile]
+  int slot = 0;
+  auto issue_read = [&](auto H_, auto R_, uint32_t sb32) {
+    constexpr int half = decltype(H_)::value, r = decltype(R_)::value;
+    if constexpr (r < 2 * NR) {
+      constexpr int i = r / 2, q = r % 2;
+      if constexpr (q == 0) tr_read<half * 512>(alo[half][i], sb32 + offA[i][0]);
+      else tr_read<half * 512>(ahi[half][i], sb32 + offA[i][1]);
+    } else {
+      constexpr int jj = (r - 2 * NR) / 2, q = r % 2;
+      if constexpr (q == 0) tr_read<half * 512>(blo[half][jj], sb32 + offB[jj][0]);
+      else tr_read<half * 512>(bhi[half][jj], sb32 + offB[jj][1]);
+    }
+  };
+  // No asm read stays in flight past the phase that issued it (for the compiler such a read is complete when issued: a copy
+  // it places at the loop's back edge, or a live-range split, would meet the old register content — mlp_wgrad_pair.h): the
+  // reads go out in front of the phase's last MFMAs and have landed by its end; the ties keep their registers allocated up to there
+  auto wait_set = [&](auto H_) {
+    constexpr int half = decltype(H_)::value;
+    static_for<0, NR>([&](auto I_) { constexpr int i = decltype(I_)::value; tr_wait<0>(alo[half][i], ahi[half][i]); });
+    static_for<0, NC>([&](auto J_) { constexpr int jj = decltype(J_)::value; tr_wait<0>(blo[half][jj], bhi[half][jj]); });
+  };
+  auto enter_tile = [&]() {   // wait for this wave's pieces of the next tile, barrier, refill the slot the barrier freed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y * PC) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_mine(islot);
+    islot = islot + 1 == R ? 0 : islot + 1;
+  };
+  // MFMAs of k-step `half` (its operand set is complete), the reads of the other set from the tile at sb_rd behind them
+  auto phase = [&](auto H_, uint32_t sb_rd) {
+    constexpr int half = decltype(H_)::value;
+    static_for<0, NMMH>([&](auto M_) {
+      constexpr int m = decltype(M_)::value;
+      constexpr int jj = m / NR, i = m % NR;
+      // (no run-time guards: a tile this wave does not own is a duplicate of its first — computed and never stored —
+      //  so that the phase stays one basic block)
+      const Frag fa = Frag{alo[half][i][0], alo[half][i][1], alo[half][i][2], alo[half][i][3],
+                           ahi[half][i][0], ahi[half][i][1], ahi[half][i][2], ahi[half][i][3]};
+      const Frag fb = Frag{blo[half][jj][0], blo[half][jj][1], blo[half][jj][2], blo[half][jj][3],
+                           bhi[half][jj][0], bhi[half][jj][1], bhi[half][jj][2], bhi[half][jj][3]};
+      acc[i][jj] = M::mma(fb, fa, acc[i][jj]);
+      if constexpr (jj == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[e];
+      }
+      if constexpr (m < NLEAD) {
+        // (unconditional, also behind the last tile, where they fetch a stale slot nobody uses: a branch here would put a
+        //  join — and the compiler's copies of the destination registers — between the reads and their wait)
+        static_for<(m * NRDH + NLEAD - 1) / NLEAD, ((m + 1) * NRDH + NLEAD - 1) / NLEAD>([&](auto R_) {
+          issue_read(std::integral_constant<int, 1 - half>{}, R_, sb_rd);
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    wait_set(std::integral_constant<int, 1 - half>{});
+  };
+  // prologue: tile 0 lands, the reads of its first k-step go to set 0
+  enter_tile();
+  static_for<0, NRDH>([&](auto R_) { issue_read(std::integral_constant<int, 0>{}, R_, lds_addr(smem)); });
+  wait_set(std::integral_constant<int, 0>{});
+  for (int64_t tile = 0; tile < L.t1; ++tile) {
+    const bool more = tile + 1 < L.t1;
+    const uint32_t sb_cur = lds_addr(smem) + slot * SLOT;
+    phase(std::integral_constant<int, 0>{}, sb_cur);
+    if (more) enter_tile();
+    slot = slot + 1 == R ? 0 : slot + 1;
+    phase(std::integral_constant<int, 1>{}, lds_addr(smem) + slot * SLOT);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing re-loads
+
+  // partial plane [nta * 32][ntb * 32] of this split, bf16 in the first half of its fp32-sized slot (wgrad_run)
+  const int NB = L.ntb_total * 32;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    if (i >= nr) continue;
+    const int rt = r0 + i;
+    const int64_t pel = (int64_t)(32 * rt + i32) * NB + 4 * g32;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      if (j >= nc) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bf16x4 h = {(__bf16)acc[i][j][4 * k], (__bf16)acc[i][j][4 * k + 1], (__bf16)acc[i][j][4 * k + 2],
+                          (__bf16)acc[i][j][4 * k + 3]};
+        *(bf16x4*)((__bf16*)L.part + pel + 32 * (c0 + j) + 8 * k) = h;
+      }
+    }
+    if (do_bias) {
+      const float bs = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      if (lane < 32) L.bias_part[32 * rt + lane] = bs;
+    }
+  }
+}
+
+// A plain job inside the layer-pair kernel's launch: the job, its network's buffers, and how its tiles go to waves.
+struct PlainJob {
+  WgradJob j;               // split_begin counts plain workgroups (0 = the launch's first plain workgroup)
+  const char* act;          // the network's forward workspace
+  const char* ws;           // ... and backward workspace (d z sections)
+  float* part;              // ... and partial-sum buffer
+  int64_t n_tiles;
+  int cols_mode;            // plain_run4
+};
+
+__device__ __forceinline__ void plain_job_run(const PlainJob& Q, int split, char* smem, int wave, int lane) {
+  const WgradJob& J = Q.j;
+  WgradLocal L;
+  L.a0_base = Q.ws + J.a[0].off; L.a0_ks = J.a[0].ks;
+  L.a1_base = Q.ws + J.a[1].off; L.a1_ks = J.a[1].ks;
+  L.b0_base = Q.act + J.b[0].off; L.b0_ks = J.b[0].ks;
+  L.b1_base = Q.act + J.b[1].off; L.b1_ks = J.b[1].ks;
+  L.a_ks = J.a_ks; L.b_ks = J.b_ks; L.ntb_total = J.ntb;
+  L.t0 = split; L.tstep = J.n_splits;
+  L.t1 = (Q.n_tiles - split + J.n_splits - 1) / J.n_splits;
+  if (L.t1 <= 0) { L.t0 = 0; L.t1 = 0; }
+  const int nta = J.nta, ntb = J.ntb;
+  L.part = Q.part + J.part_off + (int64_t)split * nta * 32 * ntb * 32;
+  L.bias_part = Q.part + J.bias_part_off + (int64_t)split * nta * 32;
+  const int per_tile = J.a_ks + J.b_ks;
+  // shapes that occur (bf16, recompute mode; rows x cols in 32-tiles; KiB = DMA pieces per tile):
+  //   8x2  d z5 x pe (20), by rows                 5x9  [d z9 | d out] x [h7 | dir] (27), by columns
+  //   1x4  d out x h9 (9), by columns              1x8  d out x h7 (17; no view directions), by columns
+  // consumers hold at most NR x NC tiles; Y tiles in flight with (Y + 2) tiles inside the 160 KiB of LDS; PL pieces of a tile
+  // issued by the loader, PC by each consumer (PL + 3 PC >= the tile's pieces)
+  if (!Q.cols_mode) {
+    plain_run4<3, 2, 4, 14, 2>(L, smem, wave, lane, 0, nta, ntb);      // 20 KiB tiles, ring of 6
+  } else if (per_tile == 27) {
+    plain_run4<5, 3, 3, 15, 4>(L, smem, wave, lane, 1, nta, ntb);      // ring of 5
+  } else if (per_tile == 9) {
+    plain_run4<1, 2, 7, 6, 1>(L, smem, wave, lane, 1, nta, ntb);       // ring of 9
+  } else {
+    plain_run4<1, 3, 4, 11, 2>(L, smem, wave, lane, 1, nta, ntb);      // 17 KiB tiles, ring of 6
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // reduce + scatter to the reference's parameter layout
 // ------------------------------------------------------------------------------------------
 template <int P> __device__ __forceinline__ int slot_true_index(int kind, int x, int L) {
@@ -429,30 +722,42 @@ template <int P> __device__ __forceinline__ int slot_true_index(int kind, int x,
 
 // One launch reduces the outputs of every job table of a backward pass (the plain pass's and the layer-pair kernel's): each
 // output carries the fields of its job it needs.
+// (round 4) one launch also covers the outputs of SEVERAL networks' backward passes (coarse + fine): an output names its
+// network, whose partial-sum buffer, G block and gradient buffer the launch holds.
 struct ReduceOut {
   WgradOut o;
   int nta, ntb, n_splits;
+  int net;          // index into ReduceArgs::nets
   int64_t part_off, bias_part_off;
 };
-constexpr int kMaxReduceOuts = 28;
+constexpr int kMaxReduceOuts = 32, kMaxReduceNets = 2;
+struct ReduceNet {
+  const float* part;
+  float* post;      // G block or null
+  float* grad;      // flat parameter gradient
+  int accumulate;
+};
 struct ReduceArgs {
   int n_outs;
   ReduceOut out[kMaxReduceOuts];
-  const float* part;
-  float* post;      // G block or null
+  ReduceNet nets[kMaxReduceNets];
 };
-inline void append_reduce(ReduceArgs& r, const WgradArgs& w) {
-  for (int i = 0; i < w.n_outs && r.n_outs < kMaxReduceOuts; ++i) {
+// false: the table is full (the caller returns an error: a dropped output would be a parameter gradient nobody writes)
+inline bool append_reduce(ReduceArgs& r, const WgradArgs& w, int net, float* grad, int accumulate) {
+  for (int i = 0; i < w.n_outs; ++i) {
+    if (r.n_outs >= kMaxReduceOuts) return false;
     ReduceOut& R = r.out[r.n_outs++];
     const WgradJob& J = w.job[w.out[i].job];
     R.o = w.out[i];
     R.nta = J.nta; R.ntb = J.ntb; R.n_splits = J.n_splits; R.part_off = J.part_off; R.bias_part_off = J.bias_part_off;
+    R.net = net;
   }
-  r.part = w.part; r.post = w.post;
+  r.nets[net] = ReduceNet{w.part, w.post, grad, accumulate};
+  return true;
 }
 
 template <int P>
-__global__ void mlp_wgrad_reduce_kernel(ReduceArgs a, float* __restrict__ grad, int accumulate) {
+__global__ void mlp_wgrad_reduce_kernel(ReduceArgs a) {
   // Every parameter element is produced by exactly one (output, row, column): without `accumulate` the result is
   // stored, not added, and the gradient buffer needs no clearing first
   // (tests/test_gpu_kernels.py: test_mlp_backward_overwrites_every_element).
@@ -462,6 +767,9 @@ __global__ void mlp_wgrad_reduce_kernel(ReduceArgs a, float* __restrict__ grad, 
   // fixed: results are deterministic.
   const ReduceOut& J = a.out[blockIdx.y];
   const WgradOut& O = J.o;
+  const ReduceNet& N = a.nets[J.net];
+  float* __restrict__ grad = N.grad;
+  const int accumulate = N.accumulate;
   const int NA = J.nta * 32, NB = J.ntb * 32, NQ = O.cols / 4;
   const int lane = threadIdx.x & 63, r = lane >> 4;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -472,7 +780,7 @@ __global__ void mlp_wgrad_reduce_kernel(ReduceArgs a, float* __restrict__ grad, 
   const int ra = live ? (int)(idx / (NQ + 1)) : 0, q = live ? (int)(idx % (NQ + 1)) : 0;
   const int n = slot_true_index<P>(O.a_kind, ra, 0) - (O.a_kind == SRC_OUT ? O.row_off : 0);
   const bool row_ok = live && n >= 0 && n < O.rows_valid;
-  float* dst = O.to_scratch ? a.post : grad;
+  float* dst = O.to_scratch ? N.post : grad;
   const bool acc = accumulate && !O.to_scratch;
   const bool is_bias = q == NQ;
   const int cb = 4 * q;
@@ -482,7 +790,7 @@ __global__ void mlp_wgrad_reduce_kernel(ReduceArgs a, float* __restrict__ grad, 
     // plane sp of this job starts at float offset part_off + sp * st; bf16 mode keeps bf16 elements in its first half
     const int64_t el = (int64_t)(O.row0 + ra) * NB + O.col0 + cb;
     auto plane = [&](int sp) -> f32x4 {
-      const float* base = a.part + J.part_off + (int64_t)sp * st;
+      const float* base = N.part + J.part_off + (int64_t)sp * st;
       if constexpr (P == kBF16) {
         const bf16x4 h = *(const bf16x4*)((const __bf16*)base + el);   // (plain load: the partials were just written; A/B −6 %)
         return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
@@ -497,7 +805,7 @@ __global__ void mlp_wgrad_reduce_kernel(ReduceArgs a, float* __restrict__ grad, 
     }
     for (; sp < J.n_splits; sp += 4) s0 += plane(sp);
   } else if (row_ok && O.bias_off >= 0) {
-    for (int sp = r; sp < J.n_splits; sp += 4) s0[0] += a.part[J.bias_part_off + (int64_t)sp * NA + O.row0 + ra];
+    for (int sp = r; sp < J.n_splits; sp += 4) s0[0] += N.part[J.bias_part_off + (int64_t)sp * NA + O.row0 + ra];
   }
   f32x4 s = s0 + s1;
 #pragma unroll
@@ -510,13 +818,12 @@ __global__ void mlp_wgrad_reduce_kernel(ReduceArgs a, float* __restrict__ grad, 
     if (O.bias_off >= 0) dst[O.bias_off + n] = acc ? dst[O.bias_off + n] + s[0] : s[0];
     return;
   }
-  float* grow = O.transposed ? dst + O.w_off + O.col_off + n : dst + O.w_off + (int64_t)n * O.ld + O.col_off;
-  const int64_t kstride = O.transposed ? O.ld : 1;
+  float* grow = dst + O.w_off + (int64_t)n * O.ld + O.col_off;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int k = slot_true_index<P>(O.b_kind, cb + e, O.L);
     if (k < 0 || k >= O.cols_valid) continue;
-    grow[k * kstride] = acc ? grow[k * kstride] + s[e] : s[e];
+    grow[k] = acc ? grow[k] + s[e] : s[e];
   }
 }
 
@@ -529,20 +836,23 @@ __global__ void mlp_wgrad_reduce_kernel(ReduceArgs a, float* __restrict__ grad, 
 // P == bf16 rounds the two weight matrices to bf16 first: the forward and dgrad kernels evaluated the layers with the
 // rounded weights, and the products restate exactly those layers.
 // ------------------------------------------------------------------------------------------
-struct PostArgs {
+struct PostNet {
   const float* params;
   const float* post;   // G [128][256], s9 [128]
   float* grad;
   int w_views, ld_views, w_feat, b_feat;   // float offsets in params / grad (ld_views = 256 + in_dir)
   int accumulate;
 };
+constexpr int kPostTiles = 104;            // workgroups per network
+struct PostArgs { PostNet net[kMaxReduceNets]; };   // blockIdx.x / kPostTiles = network
 
 template <int P> __device__ __forceinline__ float wround(float x) {
   return P == kBF16 ? (float)(__bf16)x : x;
 }
 
 template <int P>
-__global__ __launch_bounds__(256) void wgrad_post_kernel(PostArgs a) {
+__global__ __launch_bounds__(256) void wgrad_post_kernel(PostArgs pa) {
+  const PostNet& a = pa.net[blockIdx.x / kPostTiles];
   __shared__ float red[3][64][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -550,7 +860,7 @@ __global__ __launch_bounds__(256) void wgrad_post_kernel(PostArgs a) {
   const float* s9 = a.post + kPostG;
   const float* Wv = a.params + a.w_views;
   const float* Wf = a.params + a.w_feat;
-  const int t = blockIdx.x;
+  const int t = blockIdx.x % kPostTiles;
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int r0, c0;   // output tile origin
   if (t < 72) {
@@ -612,6 +922,35 @@ __global__ __launch_bounds__(256) void wgrad_post_kernel(PostArgs a) {
 
 // split-K kernel + reduce of a prepared bf16 job list (defined in mlp_bwd.hip; also serves hashgrid.hip)
 int wgrad_launch_bf16(const WgradArgs& w, int total_splits, float* grad, int accumulate, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// host: workgroups of a launch apportioned to jobs
+// ------------------------------------------------------------------------------------------
+// out[i] workgroups for job i of weight w[i], `total` in all (at least 1 and at most cap[i] each: a job cannot use more splits
+// than it has tiles), chosen to minimise the LARGEST w[i] / out[i] — the launch ends with its slowest job, and with a few
+// dozen workgroups over six jobs a proportional share rounded down leaves the smallest job 60 % over the mean (one
+// workgroup where 1.6 were due: found as the whole launch waiting for the coarse network's d out x h9 job).  Greedy: every
+// job starts with one workgroup, each further one goes to the job with the largest per-workgroup load.
+inline void apportion(const int64_t* w, const int64_t* cap, int n, int total, int* out) {
+  int assigned = 0;
+  for (int i = 0; i < n; ++i) { out[i] = 1; ++assigned; }
+  while (assigned < total) {
+    int best = -1;
+    for (int i = 0; i < n; ++i) {
+      if (out[i] >= cap[i]) continue;
+      // w[i] / out[i] > w[best] / out[best], in integers
+      if (best < 0 || w[i] * out[best] > w[best] * out[i]) best = i;
+    }
+    if (best < 0) break;
+    ++out[best]; ++assigned;
+  }
+}
+// a job's place in the launch (its first workgroup) and in the partial-sum buffer
+inline void place_job(WgradJob& J, int splits, int& split_begin, int64_t& part_off) {
+  J.n_splits = splits; J.split_begin = split_begin; split_begin += splits;
+  J.part_off = part_off; part_off += (int64_t)splits * J.nta * 32 * J.ntb * 32;
+  J.bias_part_off = part_off; part_off += (int64_t)splits * J.nta * 32;
+}
 
 // ------------------------------------------------------------------------------------------
 // host: job list
@@ -696,51 +1035,20 @@ static WgradArgs make_jobs(const snr_mlp_config* c, int64_t n_samples, int64_t* 
     out(j, 0, SPF, SRC_OUT, 0, SH, SRC_H, 0, L.w_out, kW, 0, 0, c->out_ch, kW, L.b_out);
   }
   A.n_jobs = n; A.n_outs = no;
+  if (part_floats == nullptr) return A;   // the caller assigns the splits (layer-pair launch: make_wgall_plan)
   // split-K: the kernel streams saved activations once and is bound by that stream, so every workgroup
   // gets the same number of bytes: job i receives target * bytes_i / bytes workgroups, apportioned by
   // largest remainder so that the total is exactly one workgroup per CU — measured on MI355X (bench
   // workload): 224-256 workgroups 0.57 ms wgrad + 0.04 ms reduce per step, 512 (two rounds, twice the
   // partial sums) 0.59 + 0.08, 128 0.84.  SNR_WGRAD_SPLITS overrides the total for experiments.
-  const int64_t n_steps = A.n_tiles;
-  int64_t cost = 0;
-  for (int i = 0; i < n; ++i) cost += A.job[i].a_ks + A.job[i].b_ks;
-  int target = 256;
-  {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-      target = cus;
-    else
-      (void)hipGetLastError();   // no device (size queries on a CPU-only host): keep the default
-  }
-  if (const char* e = getenv("SNR_WGRAD_SPLITS")) target = atoi(e) > 0 ? atoi(e) : target;
-  if (target < n) target = n;
-  int64_t rem[kMaxJobs];
-  int assigned = 0;
-  for (int i = 0; i < n; ++i) {
-    const int64_t num = (int64_t)target * (A.job[i].a_ks + A.job[i].b_ks);
-    int64_t s = num / cost;
-    rem[i] = num % cost;
-    if (s < 1) { s = 1; rem[i] = -1; }
-    A.job[i].n_splits = (int)s;
-    assigned += (int)s;
-  }
-  while (assigned < target) {   // hand the left-over workgroups to the largest remainders
-    int best = 0;
-    for (int i = 1; i < n; ++i) if (rem[i] > rem[best]) best = i;
-    if (rem[best] < 0) break;
-    ++A.job[best].n_splits; rem[best] = -1; ++assigned;
-  }
+  int64_t w[kMaxJobs], cap[kMaxJobs];
+  int splits[kMaxJobs];
+  for (int i = 0; i < n; ++i) { w[i] = A.job[i].a_ks + A.job[i].b_ks; cap[i] = A.n_tiles; }
+  int target = tunables().wgrad_splits > 0 ? tunables().wgrad_splits : cu_count();
+  apportion(w, cap, n, target, splits);
   int sb = 0;
   int64_t po = 0;
-  for (int i = 0; i < n; ++i) {
-    WgradJob& J = A.job[i];
-    int64_t s = J.n_splits;
-    if (s > n_steps) s = n_steps;
-    J.n_splits = (int)s; J.split_begin = sb; sb += (int)s;
-    J.part_off = po; po += s * J.nta * 32 * J.ntb * 32;
-    J.bias_part_off = po; po += s * J.nta * 32;
-  }
+  for (int i = 0; i < n; ++i) place_job(A.job[i], splits[i], sb, po);
   *part_floats = po;
   *total_splits = sb;
   return A;

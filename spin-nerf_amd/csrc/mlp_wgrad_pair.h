@@ -49,21 +49,25 @@ struct PairJob {
   int x_ks;                // 16 (hidden layer) or 4 (positional encoding)
   int slot_begin, n_splits;   // pair slots [slot_begin, slot_begin + n_splits): slot p = workgroups (16 (p / 8) + p % 8) + {0, 8}
   PairHalf a, b;
-};
-constexpr int kMaxPairs = 4;
-struct PairArgs {
-  int n_pairs;
-  PairJob job[kMaxPairs];
-  const char* act;
-  const char* ws;
-  const char* blob;      // packed weights (forward section first)
-  const float* bias;     // bias block inside the blob
-  float* part;
+  // (round 4) one launch serves the layer pairs of SEVERAL networks (coarse + fine): every job carries its network's buffers
+  const char* act;         // forward workspace
+  const char* ws;          // backward workspace
+  const char* blob;        // packed weights (forward section first)
+  const float* bias;       // bias block inside the blob
+  float* part;             // partial-sum buffer
+  unsigned* sync;          // progress words of this job's slots (pacing, see pair_run), zeroed by the backward's dgrad launch
   int64_t n_tiles;
-  int only_kind, only_pair;   // timing experiments (SNR_PAIR_KIND / SNR_PAIR_PAIR): -1 = all
-  // pacing of the two kinds of a slot (see pair_run): progress words behind the partial sums, one per slot
-  int64_t sync_off;           // float offset of the words inside `part`
-  int epoch;                  // launch counter (12 bits): a word of another launch reads as "no progress yet"
+};
+constexpr int kMaxPairs = 8, kMaxPlain = 6;   // 4 layer pairs + 3 plain jobs per network, two networks per launch
+struct PairArgs {
+  int n_pairs, n_plain;
+  PairJob job[kMaxPairs];
+  PlainJob plain[kMaxPlain];  // the jobs of the plain split-K pass (mlp_wgrad.h), run by the launch's workgroups beyond the pair slots
+  int n_slots;                // pair slots of the launch
+  int n_plain_wgs;            // plain workgroups of the launch
+#ifdef SNR_PAIR_DEBUG
+  int only_kind, only_pair;   // timing experiments (SNR_PAIR_KIND / SNR_PAIR_PAIR; debug builds only): -1 = all
+#endif
   int sync_period, sync_lead; // kind A looks every sync_period tiles and waits while it is more than sync_lead tiles ahead; 0 = off
 };
 
@@ -321,12 +325,12 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
 
   // tiles split, split + n_splits, ... (the same sequence in the kind-A and the kind-B workgroup of a slot)
   const int64_t tstep = J.n_splits;
-  const int64_t t1 = (a.n_tiles - split + tstep - 1) / tstep;   // >= 1: the host never makes more splits than tiles
+  const int64_t t1 = (J.n_tiles - split + tstep - 1) / tstep;   // >= 1: the host never makes more splits than tiles
 
   // ---- DMA: this wave's pieces wave + 4 k of X and of D, and its quarter of the flag KiB -------------------------------
-  const char* xp = a.act + J.x_off + ((int64_t)split * KX + wave) * 1024;
-  const char* dp = a.ws + J.dz_off + ((int64_t)split * 16 + wave) * 1024;
-  const char* fp = a.act + J.flag_off + (int64_t)split * 1024;
+  const char* xp = J.act + J.x_off + ((int64_t)split * KX + wave) * 1024;
+  const char* dp = J.ws + J.dz_off + ((int64_t)split * 16 + wave) * 1024;
+  const char* fp = J.act + J.flag_off + (int64_t)split * 1024;
   const int64_t xs = (int64_t)KX * 1024 * tstep, dst_ = (int64_t)16 * 1024 * tstep, fs_ = (int64_t)1024 * tstep;
   const uint32_t lane16 = (uint32_t)lane * 16u;
   // flags: the forward stores one u32x4 per lane (sample s, half g) = [g][s][word]; the LDS image is [g][word][s], so that
@@ -405,14 +409,14 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int q = 0; q < KR; ++q)
-      W[c][q] = *(const Frag*)(a.blob + (((int64_t)H.w_frag + (2 * wave + c) * KR + q) * 64 + lane) * 16);
+      W[c][q] = *(const Frag*)(J.blob + (((int64_t)H.w_frag + (2 * wave + c) * KR + q) * 64 + lane) * 16);
   // kind A: the bias of this lane's column of h_2k, 16 copies = the C operand of the rebuild chain's first MFMA (opaque to the
   // compiler, or it would re-materialise the copies in front of every use)
   f32x16 biasC[2];
   if constexpr (!PB) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const float bj = a.bias[H.bias_off + 64 * wave + 32 * c + (lane & 31)];
+      const float bj = J.bias[H.bias_off + 64 * wave + 32 * c + (lane & 31)];
 #pragma unroll
       for (int r = 0; r < 16; ++r) biasC[c][r] = bj;
       asm volatile("" : "+v"(biasC[c]));
@@ -511,7 +515,7 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
     if constexpr (d == 3 && c == 1 && part == 1) pair_operand_ready(P[0][h], P[1][h]);
   };
 
-  unsigned* sync_w = (unsigned*)(a.part + a.sync_off) + (J.slot_begin + split);   // this slot's progress word (pacing)
+  unsigned* sync_w = J.sync + split;   // this slot's progress word (pacing)
   unsigned post_word = 0, post_zero = 0;   // (VGPRs: the store's data and its zero offset)
   asm volatile("" : "+v"(post_zero));
   // One body.  FIRST = body -1: rebuilds tile 0, accumulates nothing.
@@ -649,17 +653,21 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
   // flight that it could disturb — and sleeps while it is more than sync_lead tiles ahead.  Kind A has the time: the launch
   // ends when kind B does.  The wait is bounded (a kind-B workgroup that is not resident yet must not hang the launch):
   // after 256 looks without progress kind A stops looking for the rest of the launch.
+#ifdef SNR_PAIR_DEBUG
   bool pacing = a.sync_period > 0 && a.only_kind < 0;
+#else
+  bool pacing = a.sync_period > 0;
+#endif
   for (int tile = 0, nt = (int)t1; tile < nt; ++tile) {
     if constexpr (PB) {
-      post_word = ((unsigned)a.epoch << 20) | (unsigned)tile;   // (stored behind this body's barrier: EV_SYNC)
+      post_word = (unsigned)tile + 1u;   // tiles done when the store lands (behind this body's barrier: EV_SYNC); 0 = none yet
     } else if (pacing) {
       if (tile % a.sync_period == a.sync_period - 1) {
         for (int look = 0;; ++look) {
           unsigned w;
           asm volatile("global_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(0u), "s"(sync_w) : "memory");
           w = __builtin_amdgcn_readfirstlane(w);
-          const int theirs = (int)(w >> 20) == a.epoch ? (int)(w & 0xfffffu) : -1;
+          const int theirs = (int)w - 1;
           if (tile - theirs <= a.sync_lead) break;
           if (look == 256) { pacing = false; break; }
           __builtin_amdgcn_s_sleep(32);
@@ -676,7 +684,7 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
   //   kind A: plane [256 d z_{2k+1} slots][256 columns j of h_2k]: lane (slot 32 m + lane & 31, half gg) holds columns
   //           64 wave + 32 c + 8 k + 4 gg + 0..3
   constexpr int NB = PB ? 32 * NM : 256;
-  __bf16* plane = (__bf16*)(a.part + H.part_off + (int64_t)split * 256 * NB);
+  __bf16* plane = (__bf16*)(J.part + H.part_off + (int64_t)split * 256 * NB);
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int64_t col = 64 * wave + 32 * c + (lane & 31);
@@ -689,7 +697,7 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
         else *(bf16x4*)(plane + (int64_t)(32 * m + (lane & 31)) * NB + 64 * wave + 32 * c + 8 * k + 4 * gg) = h;
       }
   }
-  float* bp = a.part + H.bias_part_off + (int64_t)split * 256;
+  float* bp = J.part + H.bias_part_off + (int64_t)split * 256;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const float bs = bsum[c] + __shfl_xor(bsum[c], 32, 64);
@@ -702,15 +710,33 @@ __global__ __launch_bounds__(64 * kPairWaves) void mlp_wgrad_pair_kernel(PairArg
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Roles.  Blocks come in groups of 16: block 16 g + c (c < 8) is kind A, block 16 g + 8 + c kind B of pair slot 8 g + c —
+  // the two kinds of a slot are the blocks b and b ^ 8, same XCD.  Every block whose slot number is not below n_slots is
+  // a PLAIN workgroup (the split-K jobs of mlp_wgrad.h: stream-bound work on its own CUs beside the matrix-bound slots),
+  // numbered in block order.
   const int b = blockIdx.x;
-  const int kind = (b >> 3) & 1;                 // workgroups b and b ^ 8 (same XCD) are the two kinds of one slot
-  const int p = (b >> 4) * 8 + (b & 7);
+  const int grp = b >> 4, kind = (b >> 3) & 1, col = b & 7;
+  const int p = grp * 8 + col;
+  if (p >= a.n_slots) {
+    const int full = a.n_slots >> 3, rem = a.n_slots & 7;
+    const int q = grp == full ? kind * (8 - rem) + (col - rem) : (rem ? 2 * (8 - rem) : 0) + (b - 16 * (full + (rem ? 1 : 0)));
+    if (q >= a.n_plain_wgs) return;
+#ifdef SNR_PAIR_DEBUG
+    if (a.only_kind == 3 || (a.only_kind >= 0 && a.only_kind < 2)) return;   // timing experiments: 3 = no plain workgroups, 2 = only them
+#endif
+    int qi = 0;
+    while (qi + 1 < a.n_plain && a.plain[qi + 1].j.split_begin <= q) ++qi;
+    plain_job_run(a.plain[qi], q - a.plain[qi].j.split_begin, smem, wave, lane);
+    return;
+  }
   int ji = 0;
   while (ji + 1 < a.n_pairs && a.job[ji + 1].slot_begin <= p) ++ji;
   const PairJob& J = a.job[ji];
   const int split = p - J.slot_begin;
   if (split >= J.n_splits) return;               // (slots beyond the last job)
-  if ((a.only_kind >= 0 && kind != a.only_kind) || (a.only_pair >= 0 && ji != a.only_pair)) return;
+#ifdef SNR_PAIR_DEBUG
+  if (a.only_kind == 2 || (a.only_kind >= 0 && a.only_kind < 2 && kind != a.only_kind) || (a.only_pair >= 0 && ji != a.only_pair)) return;
+#endif
   // kind A is compiled once per wave (its row sums), kind B once
 #define SNR_PAIR_A(KX_) \
   do { \
@@ -741,108 +767,183 @@ __global__ __launch_bounds__(64 * kPairWaves) void mlp_wgrad_pair_kernel(PairArg
 namespace snr {
 
 // ------------------------------------------------------------------------------------------
-// host: the four layer pairs, their slots, and the reduce table of their partial sums
+// host: ONE weight-gradient launch for the backward passes of one or two networks (coarse + fine) — their layer pairs on
+// the pair slots, their plain jobs on the remaining workgroups — and the reduce tables of its partial sums
 // ------------------------------------------------------------------------------------------
-struct PairPlan {
-  PairArgs pa;          // kernel arguments (pointers still to be filled in)
-  WgradArgs red;        // reduce / scatter table over the pair kernel's partial planes (mlp_wgrad_reduce_kernel)
-  int grid;             // workgroups of the pair kernel
-  int64_t part_floats;  // floats of partial sums behind part_base
+struct WgNet {            // one network's part of the launch
+  const snr_mlp_config* c;
+  int64_t n_samples;
+  // filled by make_wgall_plan
+  WgradArgs plain;        // its plain jobs (job + output tables; offsets inside its partial-sum buffer)
+  WgradArgs red;          // reduce / scatter table over its layer pairs' partial planes
+  int64_t part_floats;    // floats of its partial-sum buffer: plain planes | pair planes | progress words
+  int64_t sync_off;       // float offset of its progress words (kSyncWords of them)
+};
+constexpr int kSyncWords = 256;      // progress words reserved per network (>= its pair slots: n_slots is clamped to 128)
+constexpr int kMaxPairSlots = 128;
+struct WgAllPlan {
+  PairArgs pa;            // kernel arguments (pointers still to be filled in: fill_wgall_pointers)
+  int grid;               // workgroups of the launch
+  int pair_job0[kMaxReduceNets], plain_job0[kMaxReduceNets];   // first pair / plain job of each network inside `pa`
 };
 
-// part_base: floats of the partial-sum buffer already taken by the plain pass
-inline PairPlan make_pair_plan(const snr_mlp_config* c, int64_t n_samples, int64_t part_base) {
+// workgroups of the launch: pair slots and plain workgroups (tunables: SNR_PAIR_SLOTS, SNR_PLAIN_WGS).  Default: of the
+// device's CUs, 5 in 32 run plain jobs (256 CUs: 108 pair slots = 216 CUs + 40 plain CUs) — swept on MI355X,
+// profiles/r04_wgall_tuning.txt.
+inline void wgall_shape(int* n_slots, int* n_plain) {
+  const int cus = cu_count();
+  int slots = tunables().pair_slots > 0 ? tunables().pair_slots : (cus * 27 / 32) / 2;
+  if (slots > kMaxPairSlots) slots = kMaxPairSlots;
+  if (slots < kMaxPairs) slots = kMaxPairs;
+  int plain = tunables().plain_wgs > 0 ? tunables().plain_wgs : cus - 2 * slots;
+  if (plain < kMaxPlain) plain = kMaxPlain;
+  if (plain > 256) plain = 256;
+  *n_slots = slots; *n_plain = plain;
+}
+
+// upper bound of a network's partial-sum floats in ANY launch it may take part in (alone or merged with another network):
+// every split of every job is at most the largest plane of its kind
+inline int64_t wgall_part_bound() {
+  int n_slots, n_plain;
+  wgall_shape(&n_slots, &n_plain);
+  const int64_t pair_split = 2 * (256 * 256 + 256);        // kind A + kind B planes of a hidden layer pair, with their bias rows
+  const int64_t plain_split = 160 * 288 + 160;             // [d z9 | d out] x [h7 | dir]: 5 x 9 tiles
+  return (int64_t)(n_slots + kMaxPairs) * pair_split + (int64_t)(n_plain + kMaxPlain) * plain_split + kSyncWords;
+}
+
+inline int make_wgall_plan(WgNet* nets, int n_nets, WgAllPlan& Pl) {
   using B = Blob<kBF16>;
   constexpr int SPF = 2 * Prec<kBF16>::EPF;
-  const int vd = c->use_viewdirs;
-  const ParamLayout L = make_param_layout(c->multires, c->multires_views, vd, c->out_ch, c->i_embed == -1);
-  const PackTable T = make_pack_table<kBF16>(c->multires, c->multires_views, vd, c->out_ch, c->i_embed == -1);
-  const ActLayout<kBF16> AL(n_samples, vd);
-  const WsLayout<kBF16> WL(n_samples, vd);
-  const int L_pts = c->i_embed == -1 ? 0 : c->multires;
-  const int ip = L.in_pts;
-  PairPlan Pl{};
+  Pl = WgAllPlan{};
   PairArgs& A = Pl.pa;
-  WgradArgs& R = Pl.red;
-  A.n_pairs = kMaxPairs;
-  A.n_tiles = AL.n_tiles;
-  A.only_kind = getenv("SNR_PAIR_KIND") ? atoi(getenv("SNR_PAIR_KIND")) : -1;
-  A.only_pair = getenv("SNR_PAIR_PAIR") ? atoi(getenv("SNR_PAIR_PAIR")) : -1;
-  R.n_tiles = AL.n_tiles;
-  // slots: one kind-A and one kind-B workgroup each, all CUs busy; apportioned by the MFMAs per tile of a pair
-  // (pair 0 rebuilds from / accumulates against the 64-wide encoding: (8 + 32) + (32 + 8) of the (32 + 32) x 2 of the others)
-  int cus = 256;
-  {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-    else (void)hipGetLastError();
+  int n_slots, n_plain;
+  wgall_shape(&n_slots, &n_plain);
+  const int w0 = tunables().pair_w0 > 0 ? tunables().pair_w0 : 80;   // cost of pair 0 relative to 100 of the others (swept: profiles/r03_pair_tuning.txt)
+
+  // ---- the jobs of every network: plain jobs (no splits yet), layer pairs ----
+  int64_t pw[kMaxPairs], pcap[kMaxPairs], qw[kMaxPlain], qcap[kMaxPlain];
+  int np = 0, nq = 0;
+  for (int i = 0; i < n_nets; ++i) {
+    WgNet& N = nets[i];
+    N.plain = make_jobs<kBF16>(N.c, N.n_samples, nullptr, nullptr, true);
+    Pl.pair_job0[i] = np; Pl.plain_job0[i] = nq;
+    if (N.plain.n_jobs > kMaxPlain - nq) return SNR_ERR_UNSUPPORTED;
+    for (int j = 0; j < N.plain.n_jobs; ++j) {
+      qw[nq] = (int64_t)(N.plain.job[j].a_ks + N.plain.job[j].b_ks) * N.plain.n_tiles;   // bytes streamed
+      qcap[nq++] = N.plain.n_tiles;
+    }
+    for (int k = 0; k < 4; ++k) {
+      pw[np] = (int64_t)(k == 0 ? w0 : 100) * N.plain.n_tiles;   // MFMAs: pair 0 works on the 64-wide encoding
+      pcap[np++] = N.plain.n_tiles;
+    }
   }
-  int n_slots = cus / 2;
-  if (const char* e = getenv("SNR_PAIR_SLOTS")) n_slots = atoi(e) > 0 ? atoi(e) : n_slots;
-  if (n_slots < kMaxPairs) n_slots = kMaxPairs;
-  int w0 = 80;   // cost of pair 0 relative to 100 of the others (swept on the GPU: 66 .. 86, profiles/r03_pair_tuning.txt)
-  if (const char* e = getenv("SNR_PAIR_W0")) w0 = atoi(e) > 0 ? atoi(e) : w0;
-  const int wsum = w0 + 300;
-  int splits[kMaxPairs];
-  int used = 0;
-  for (int k = 0; k < kMaxPairs; ++k) {
-    splits[k] = n_slots * (k == 0 ? w0 : 100) / wsum;
-    if (splits[k] < 1) splits[k] = 1;
-    used += splits[k];
+  int psplit[kMaxPairs], qsplit[kMaxPlain];
+  apportion(pw, pcap, np, n_slots, psplit);
+  apportion(qw, qcap, nq, n_plain, qsplit);
+
+  // ---- placement: plain workgroups / pair slots in job order; every network's partial planes in its own buffer ----
+  int slot = 0, qwg = 0;
+  for (int i = 0; i < n_nets; ++i) {
+    WgNet& N = nets[i];
+    const snr_mlp_config* c = N.c;
+    const int vd = c->use_viewdirs;
+    const ParamLayout L = make_param_layout(c->multires, c->multires_views, vd, c->out_ch, c->i_embed == -1);
+    const PackTable T = make_pack_table<kBF16>(c->multires, c->multires_views, vd, c->out_ch, c->i_embed == -1);
+    const ActLayout<kBF16> AL(N.n_samples, vd);
+    const WsLayout<kBF16> WL(N.n_samples, vd);
+    const int L_pts = c->i_embed == -1 ? 0 : c->multires;
+    const int ip = L.in_pts;
+    int64_t po = 0;
+    for (int j = 0; j < N.plain.n_jobs; ++j) {
+      PlainJob& Q = A.plain[Pl.plain_job0[i] + j];
+      place_job(N.plain.job[j], qsplit[Pl.plain_job0[i] + j], qwg, po);
+      Q.j = N.plain.job[j];
+      Q.n_tiles = N.plain.n_tiles;
+      // by rows when the job has more than four row tiles (d z5 x pe), else by columns (mlp_wgrad.h: plain_run4)
+      Q.cols_mode = !(Q.j.nta == 8 && Q.j.ntb == 2);
+      // (the shapes plain_job_run is instantiated for: its loader's counted wait is an immediate per tile size)
+      const int kib = Q.j.a_ks + Q.j.b_ks;
+      if (Q.cols_mode ? !((kib == 27 && Q.j.nta == 5 && Q.j.ntb == 9) || (kib == 9 && Q.j.nta == 1 && Q.j.ntb == 4) ||
+                          (kib == 17 && Q.j.nta == 1 && Q.j.ntb == 8))
+                      : kib != 20)
+        return SNR_ERR_UNSUPPORTED;
+    }
+    WgradArgs& R = N.red;
+    R = WgradArgs{};
+    R.n_tiles = AL.n_tiles;
+    int nj = 0, no = 0;
+    const int n_fwd_entries = 8 + (vd ? 4 : 1), n_top_bwd = vd ? 3 : 1;
+    for (int k = 0; k < 4; ++k) {
+      PairJob& J = A.job[Pl.pair_job0[i] + k];
+      const int la = 2 * k, lb = 2 * k + 1;   // rebuilt / accumulated layers: kind A rebuilds h_{la}, accumulates dW_{lb}
+      J.x_ks = k == 0 ? B::KS_PE : B::KS_H;
+      J.x_off = k == 0 ? AL.off_pe() : AL.off_h(la - 1);
+      J.dz_off = WL.off_dz(lb);
+      J.flag_off = AL.off_mask(la);
+      J.n_tiles = AL.n_tiles;
+      const int64_t s = psplit[Pl.pair_job0[i] + k];
+      J.slot_begin = slot; J.n_splits = (int)s; slot += (int)s;
+      const int NMb = J.x_ks / 2;
+      J.a.w_frag = T.e[la].frag_begin;
+      J.a.bias_off = bias_off_stage(la);
+      J.b.w_frag = T.e[n_fwd_entries + n_top_bwd + (7 - lb)].frag_begin;
+      J.b.bias_off = 0;
+      J.a.part_off = po; po += s * 256 * 256;
+      J.a.bias_part_off = po; po += s * 256;
+      J.b.part_off = po; po += s * 256 * 32 * NMb;
+      J.b.bias_part_off = po; po += s * 256;
+      // reduce table: kind A planes [row = d z_{lb} slot][column j of h_{la} (true order)] -> dW_{lb}[true(row)][j], row sums -> db_{lb}
+      auto rjob = [&](int nta, int ntb, int64_t part_off, int64_t bias_part_off) {
+        WgradJob& Q = R.job[nj];
+        Q.nta = nta; Q.ntb = ntb; Q.n_splits = (int)s; Q.split_begin = 0; Q.part_off = part_off; Q.bias_part_off = bias_part_off;
+        return nj++;
+      };
+      auto rout = [&](int j, int rows, int a_kind, int cols, int b_kind, int Lenc, int64_t w_off, int ld, int col_off,
+                      int rows_valid, int cols_valid, int64_t bias_off) {
+        WgradOut& O = R.out[no++];
+        O.job = j; O.row0 = 0; O.rows = rows; O.a_kind = a_kind; O.col0 = 0; O.cols = cols; O.b_kind = b_kind; O.L = Lenc;
+        O.w_off = (int)w_off; O.ld = ld; O.col_off = col_off; O.row_off = 0; O.rows_valid = rows_valid; O.cols_valid = cols_valid;
+        O.bias_off = (int)bias_off; O.to_scratch = 0;
+      };
+      const int ld_b = lb == kSkip + 1 ? kW + ip : kW, co_b = lb == kSkip + 1 ? ip : 0;
+      int j = rjob(8, 8, J.a.part_off, J.a.bias_part_off);
+      rout(j, kW, SRC_H, kW, SRC_NAT, 0, L.w_pts[lb], ld_b, co_b, kW, kW, L.b_pts[lb]);
+      // kind B planes [neuron n of layer la (true order)][row = X slot] -> dW_{la}[n][true(row)], column sums -> db_{la}
+      j = rjob(8, NMb, J.b.part_off, J.b.bias_part_off);
+      if (k == 0) rout(j, kW, SRC_NAT, 32 * NMb, SRC_ENC_PTS, L_pts, L.w_pts[la], ip, 0, kW, ip, L.b_pts[la]);
+      else rout(j, kW, SRC_NAT, 32 * NMb, SRC_H, 0, L.w_pts[la], kW, 0, kW, kW, L.b_pts[la]);
+    }
+    R.n_jobs = nj; R.n_outs = no;
+    N.sync_off = po; po += kSyncWords;
+    N.part_floats = po;
   }
-  for (int k = kMaxPairs - 1; used < n_slots; k = k == 1 ? kMaxPairs - 1 : k - 1) { ++splits[k]; ++used; }   // left-overs to the heavy pairs
-  int slot = 0, nj = 0, no = 0;
-  int64_t po = part_base;
-  const int n_fwd_entries = 8 + (vd ? 4 : 1), n_top_bwd = vd ? 3 : 1;
-  for (int k = 0; k < kMaxPairs; ++k) {
-    PairJob& J = A.job[k];
-    const int la = 2 * k, lb = 2 * k + 1;   // rebuilt / accumulated layers: kind A rebuilds h_{la}, accumulates dW_{lb}
-    J.x_ks = k == 0 ? B::KS_PE : B::KS_H;
-    J.x_off = k == 0 ? AL.off_pe() : AL.off_h(la - 1);
-    J.dz_off = WL.off_dz(lb);
-    J.flag_off = AL.off_mask(la);
-    int64_t s = splits[k];
-    if (s > A.n_tiles) s = A.n_tiles;
-    J.slot_begin = slot; J.n_splits = (int)s; slot += (int)s;
-    const int NMb = J.x_ks / 2;
-    J.a.w_frag = T.e[la].frag_begin;
-    J.a.bias_off = bias_off_stage(la);
-    J.b.w_frag = T.e[n_fwd_entries + n_top_bwd + (7 - lb)].frag_begin;
-    J.b.bias_off = 0;
-    J.a.part_off = po; po += s * 256 * 256;
-    J.a.bias_part_off = po; po += s * 256;
-    J.b.part_off = po; po += s * 256 * 32 * NMb;
-    J.b.bias_part_off = po; po += s * 256;
-    // reduce table: kind A planes [row = d z_{lb} slot][column j of h_{la} (true order)] -> dW_{lb}[true(row)][j], row sums -> db_{lb}
-    auto rjob = [&](int nta, int ntb, int64_t part_off, int64_t bias_part_off) {
-      WgradJob& Q = R.job[nj];
-      Q.nta = nta; Q.ntb = ntb; Q.n_splits = (int)s; Q.split_begin = 0; Q.part_off = part_off; Q.bias_part_off = bias_part_off;
-      return nj++;
-    };
-    auto rout = [&](int j, int rows, int a_kind, int cols, int b_kind, int Lenc, int64_t w_off, int ld, int col_off,
-                    int rows_valid, int cols_valid, int64_t bias_off, int transposed) {
-      WgradOut& O = R.out[no++];
-      O.job = j; O.row0 = 0; O.rows = rows; O.a_kind = a_kind; O.col0 = 0; O.cols = cols; O.b_kind = b_kind; O.L = Lenc;
-      O.w_off = (int)w_off; O.ld = ld; O.col_off = col_off; O.row_off = 0; O.rows_valid = rows_valid; O.cols_valid = cols_valid;
-      O.bias_off = (int)bias_off; O.to_scratch = 0; O.transposed = transposed;
-    };
-    const int ld_b = lb == kSkip + 1 ? kW + ip : kW, co_b = lb == kSkip + 1 ? ip : 0;
-    int j = rjob(8, 8, J.a.part_off, J.a.bias_part_off);
-    rout(j, kW, SRC_H, kW, SRC_NAT, 0, L.w_pts[lb], ld_b, co_b, kW, kW, L.b_pts[lb], 0);
-    // kind B planes [neuron n of layer la (true order)][row = X slot] -> dW_{la}[n][true(row)], column sums -> db_{la}
-    j = rjob(8, NMb, J.b.part_off, J.b.bias_part_off);
-    if (k == 0) rout(j, kW, SRC_NAT, 32 * NMb, SRC_ENC_PTS, L_pts, L.w_pts[la], ip, 0, kW, ip, L.b_pts[la], 0);
-    else rout(j, kW, SRC_NAT, 32 * NMb, SRC_H, 0, L.w_pts[la], kW, 0, kW, kW, L.b_pts[la], 0);
+  A.n_pairs = np; A.n_plain = nq;
+  A.n_slots = slot;            // (== n_slots unless a network has fewer tiles than its share of the slots)
+  A.n_plain_wgs = qwg;
+  // grid: whole groups of 16 for the slots; the plain workgroups take the non-slot blocks of the last group, then new blocks
+  const int full = slot >> 3, rem = slot & 7;
+  const int in_group = rem ? 2 * (8 - rem) : 0;
+  Pl.grid = 16 * (full + (rem ? 1 : 0)) + (qwg > in_group ? qwg - in_group : 0);
+#ifdef SNR_PAIR_DEBUG
+  A.only_kind = tunables().only_kind; A.only_pair = tunables().only_pair;
+#endif
+  A.sync_period = tunables().pair_poll; A.sync_lead = tunables().pair_lead;
+  return SNR_OK;
+}
+
+// pointers of network `i` into the kernel arguments (its jobs were placed by make_wgall_plan)
+inline void fill_wgall_pointers(WgAllPlan& Pl, const WgNet* nets, int i, const char* act, const char* ws, const char* blob,
+                                const float* bias, float* part) {
+  const WgNet& N = nets[i];
+  for (int k = 0; k < 4; ++k) {
+    PairJob& J = Pl.pa.job[Pl.pair_job0[i] + k];
+    J.act = act; J.ws = ws; J.blob = blob; J.bias = bias; J.part = part;
+    J.sync = (unsigned*)(part + N.sync_off) + (J.slot_begin - Pl.pa.job[Pl.pair_job0[i]].slot_begin);
   }
-  R.n_jobs = nj; R.n_outs = no;
-  Pl.grid = 16 * ((slot + 7) / 8);   // slot p = workgroups 16 (p / 8) + p % 8 and + 8
-  A.sync_off = po; po += 256;   // progress words of the slots (pacing of the two kinds)
-  static int launch_epoch = 0;
-  A.epoch = (launch_epoch = (launch_epoch + 1) & 0xfff);
-  A.sync_period = getenv("SNR_PAIR_POLL") ? atoi(getenv("SNR_PAIR_POLL")) : 16;
-  A.sync_lead = getenv("SNR_PAIR_LEAD") ? atoi(getenv("SNR_PAIR_LEAD")) : 2;
-  Pl.part_floats = po - part_base;
-  return Pl;
+  for (int j = 0; j < N.plain.n_jobs; ++j) {
+    PlainJob& Q = Pl.pa.plain[Pl.plain_job0[i] + j];
+    Q.act = act; Q.ws = ws; Q.part = part;
+  }
 }
 
 }  // namespace snr

@@ -46,12 +46,57 @@ template <auto Kernel> inline int ensure_dynamic_lds(int bytes) {
   return 0;
 }
 
-// bf16 training saves only the odd hidden layers / odd d z and rebuilds the even ones inside the weight-gradient pass
-// (mlp_wgrad_pair.h).  SNR_RECOMPUTE=0 selects the plain pass (every layer saved) for A/B measurements; the forward and
-// the backward of one step must see the same setting.
-inline bool recompute_enabled() {
+// ---- process-wide settings, read ONCE --------------------------------------------------------------------------------
+// The SNR_* environment switches (A/B experiments) and the CU count of each device are read at the first call that needs
+// them and cached — not on every launch.  snr_tunables_reload() (include/spinnerf_hip.h, diagnostics)
+// re-reads the environment for tests and A/B scripts that change it inside one process.
+struct Tunables {
+  // bf16 training saves only the odd hidden layers / odd d z and rebuilds the even ones inside the weight-gradient pass
+  // (mlp_wgrad_pair.h).  SNR_RECOMPUTE=0 selects the plain pass (every layer saved) for A/B measurements; the forward and
+  // the backward of one step must see the same setting.
+  bool recompute;
+  int wgrad_splits;          // SNR_WGRAD_SPLITS: workgroups of the stand-alone plain split-K kernel (0 = one per CU)
+  int pair_slots;            // SNR_PAIR_SLOTS: pair slots of the layer-pair launch (0 = default share of the CUs)
+  int plain_wgs;             // SNR_PLAIN_WGS: plain workgroups inside the layer-pair launch (0 = the CUs the slots leave)
+  int pair_w0;               // SNR_PAIR_W0: slot weight of pair 0 (others = 100)
+  int pair_poll, pair_lead;  // SNR_PAIR_POLL / SNR_PAIR_LEAD: pacing of the two kinds of a slot
+  int only_kind, only_pair;  // SNR_PAIR_KIND / SNR_PAIR_PAIR (debug builds of the pair kernel only)
+  int merge_nets;            // SNR_MERGE_NETS=0: one backward launch sequence per network (A/B against the merged one)
+};
+inline Tunables read_tunables() {
+  auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
+  Tunables t{};
   const char* e = getenv("SNR_RECOMPUTE");
-  return !(e && e[0] == '0');
+  t.recompute = !(e && e[0] == '0');
+  t.wgrad_splits = geti("SNR_WGRAD_SPLITS", 0);
+  t.pair_slots = geti("SNR_PAIR_SLOTS", 0);
+  t.plain_wgs = geti("SNR_PLAIN_WGS", 0);
+  t.pair_w0 = geti("SNR_PAIR_W0", 0);
+  t.pair_poll = geti("SNR_PAIR_POLL", 16);
+  t.pair_lead = geti("SNR_PAIR_LEAD", 2);
+  t.only_kind = geti("SNR_PAIR_KIND", -1);
+  t.only_pair = geti("SNR_PAIR_PAIR", -1);
+  t.merge_nets = geti("SNR_MERGE_NETS", 1);
+  return t;
+}
+inline Tunables& tunables_storage() { static Tunables t = read_tunables(); return t; }   // (thread-safe initialisation)
+inline const Tunables& tunables() { return tunables_storage(); }
+inline bool recompute_enabled() { return tunables().recompute; }
+
+// CUs of the current device (cached per device ordinal; 256 when no device is present: size queries on a CPU-only host)
+inline int cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+  std::atomic<int>& c = cache[dev & 63];
+  int n = c.load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  c.store(n, std::memory_order_relaxed);
+  return n;
 }
 
 // ---- MFMA policies --------------------------------------------------------------------------

@@ -427,6 +427,28 @@ def mlp_train_backward(net, saved, d_raw):
     return g
 
 
+def mlp_train_backward_multi(nets, saveds, d_raws):
+    """The backward passes of several NeRF MLPs as ONE launch sequence (snr_mlp_backward_multi): one chain launch, one
+    weight-gradient launch, one reduce for all of them.  Returns the flat gradients in the order of ``nets``."""
+    import ctypes
+    lib = _lib.load()
+    items = (_lib.MlpBwdItem * len(nets))()
+    keep, grads = [], []
+    for i, (net, (packed, act, n), d_raw) in enumerate(zip(nets, saveds, d_raws)):
+        cfg = net.cfg
+        g = torch.empty_like(net.flat.data)
+        ws_bytes = lib.snr_mlp_bwd_ws_bytes(cfg, n)
+        if ws_bytes <= 0:
+            check(int(ws_bytes), "snr_mlp_bwd_ws_bytes")
+        ws = torch.empty(ws_bytes, device=g.device, dtype=torch.uint8)
+        items[i] = _lib.MlpBwdItem(ctypes.pointer(cfg), ptr(packed), ptr(net.flat.detach()), ptr(d_raw), n, ptr(act), ptr(ws),
+                                   ptr(g), 0)
+        keep.append((ws, d_raw, packed, act))
+        grads.append(g)
+    check(lib.snr_mlp_backward_multi(items, len(nets), stream()), "snr_mlp_backward_multi")
+    return grads
+
+
 # ----------------------------------------------------------------------------------------------
 # render_rays as one library call (snr_render_rays_fused_*): the training step's launch sequence is enqueued by the
 # library, every intermediate lives in one workspace

@@ -165,17 +165,24 @@ class RenderTrainer:
             h = ops.fused_forward(net_c, net_f if two else None, rays, Nc, Nf, lindisp, white, perturb, std, seed, self._draws,
                                   target, loss, randoms=rnd)   # local mean: Adam folds 1 / world_size in
             self._draws += 4
-            g_c = torch.empty_like(net_c.flat.data)
             if two:
-                g_f = torch.empty_like(net_f.flat.data)
-                ops.fused_backward(h, g_c, g_f, passes=ops.PASS_FINE)
+                # both backward passes as ONE launch sequence (snr_mlp_backward_multi: one chain launch, one weight-gradient
+                # launch, one reduce for the two networks); the two gradients are halves of one buffer, so that data-parallel
+                # ranks exchange them with a single all-reduce
+                n_c = net_c.flat.numel()
+                g_both = torch.empty(n_c + net_f.flat.numel(), device=net_c.flat.device, dtype=net_c.flat.dtype)
+                g_c, g_f = g_both[:n_c], g_both[n_c:]
+                ops.fused_backward(h, g_c, g_f)
                 net_f.flat.grad = g_f
-                if self.world_size > 1:     # the fine net's all-reduce runs under the coarse backward
-                    self._start_all_reduce(self.nets.index(net_f), net_f.flat)
-                ops.fused_backward(h, g_c, g_f, passes=ops.PASS_COARSE)
+                net_c.flat.grad = g_c
+                if self.world_size > 1 and os.environ.get("SNR_SPLIT_ALLREDUCE") != "1":
+                    import torch.distributed as dist
+                    work = dist.all_reduce(g_both, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    self._works[self.nets.index(net_c)] = self._works[self.nets.index(net_f)] = work
             else:
+                g_c = torch.empty_like(net_c.flat.data)
                 ops.fused_backward(h, g_c)
-            net_c.flat.grad = g_c
+                net_c.flat.grad = g_c
             self.apply_gradients()
             return loss[0], h.rgb
 
@@ -206,12 +213,18 @@ class RenderTrainer:
             out_f = ops.composite_train(raw_f, z_f, rays, target, loss[0:1], loss[1:2], noise=n_f, noise_std=std, seed=seed,
                                         offset=draw(), white_bkgd=white)
             rgb = out_f[0]
-            g_f = ops.mlp_train_backward(net_f, sv_f, out_f[5])
-            if net_f is not net_c:
+            from .nerf import NeRF
+            if net_f is not net_c and type(net_f) is NeRF and type(net_c) is NeRF:
+                # both backward passes as one launch sequence, exactly like the fused library call (fused.cpp)
+                g_f, g_c = ops.mlp_train_backward_multi([net_f, net_c], [sv_f, sv_c], [out_f[5], out_c[5]])
                 net_f.flat.grad = g_f
-                if self.world_size > 1:     # like the autograd hook: the fine net's all-reduce runs under the coarse backward
-                    self._start_all_reduce(self.nets.index(net_f), net_f.flat)
-            g_c = ops.mlp_train_backward(net_c, sv_c, out_c[5])
+            else:
+                g_f = ops.mlp_train_backward(net_f, sv_f, out_f[5])
+                if net_f is not net_c:
+                    net_f.flat.grad = g_f
+                    if self.world_size > 1:     # like the autograd hook: the fine net's all-reduce runs under the coarse backward
+                        self._start_all_reduce(self.nets.index(net_f), net_f.flat)
+                g_c = ops.mlp_train_backward(net_c, sv_c, out_c[5])
             net_c.flat.grad = g_c + g_f if net_f is net_c else g_c
         else:
             net_c.flat.grad = ops.mlp_train_backward(net_c, sv_c, out_c[5])

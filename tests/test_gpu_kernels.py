@@ -333,9 +333,12 @@ def test_pair_kernel_pacing_does_not_change_the_gradient(S, monkeypatch):
             monkeypatch.delenv("SNR_PAIR_POLL", raising=False); monkeypatch.delenv("SNR_PAIR_LEAD", raising=False)
         else:
             monkeypatch.setenv("SNR_PAIR_POLL", poll); monkeypatch.setenv("SNR_PAIR_LEAD", lead)
+        S._lib.load().snr_tunables_reload()      # the library reads its SNR_* switches once; this re-reads them
         _, net = _mlp_grad_case(S, True, "bf16", 256, 192, seed=11, wild=False, mlp=O.nerf_forward_bf16emu)
         torch.cuda.synchronize()
         grads.append(net.flat.grad.detach().clone())
+    monkeypatch.delenv("SNR_PAIR_POLL", raising=False); monkeypatch.delenv("SNR_PAIR_LEAD", raising=False)
+    S._lib.load().snr_tunables_reload()
     assert torch.isfinite(grads[0]).all()
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
 

@@ -141,8 +141,30 @@ def test_autograd_free_step_equals_the_autograd_step(monkeypatch, precision, Nf)
         if nb.flat.grad is None:
             continue
         rel = float((na.flat.grad - nb.flat.grad).norm() / nb.flat.grad.norm())
-        assert rel < 1e-5, rel
+        # fp32: the two routes differ by summation order only.  bf16 with two networks: the direct step runs BOTH backward
+        # passes as one launch sequence (snr_mlp_backward_multi), autograd one network at a time — the samples are split over
+        # the workgroups differently, and bf16 mode rounds every split-K partial sum once to bf16: a different split moves
+        # the gradient by up to 2.6e-3 of its norm (tests/test_gpu_fullsize.py: test_split_gradient_equals_whole, gate 6e-3)
+        assert rel < (6e-3 if precision == "bf16" and Nf > 0 else 1e-5), rel
         assert float((na.flat.detach() - nb.flat.detach()).abs().max()) < 2e-3   # (Adam: sign of rounding-level gradients)
+    if precision == "bf16" and Nf > 0:
+        # ... and with the merged launch sequence switched off the two routes take the same launches again: 1e-5
+        monkeypatch.delenv("SNR_NO_DIRECT_STEP")
+        monkeypatch.setenv("SNR_MERGE_NETS", "0")
+        S_ = importlib.import_module("spin-nerf_amd")
+        S_._lib.load().snr_tunables_reload()
+        try:
+            (c, d), hwf, rays, target, rnd2 = _two_trainers(precision, Nf)
+            rnd2 = {k: v for k, v in rnd2.items() if v is not None}
+            c[0].step(*hwf, rays, target, randoms=rnd2)
+            monkeypatch.setenv("SNR_NO_DIRECT_STEP", "1")
+            d[0].step(*hwf, rays, target, randoms=rnd2)
+            for nc_, nd_ in zip(c[1], d[1]):
+                rel = float((nc_.flat.grad - nd_.flat.grad).norm() / nd_.flat.grad.norm())
+                assert rel < 1e-5, rel
+        finally:
+            monkeypatch.delenv("SNR_MERGE_NETS")
+            S_._lib.load().snr_tunables_reload()
 
 
 def test_in_kernel_random_draws():
