@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SNR_ABI_VERSION 3   /* 2: snr_mlp_backward / snr_pack_rays argument lists, snr_net / snr_step_state (round 2)
-                             * 3: snr_mlp_backward_multi, snr_render_ws_layout.bwd_ws0, snr_tunables_reload (round 4) */
+                             * 3: snr_mlp_backward_multi, snr_adam_pack_multi, snr_render_ws_layout.bwd_ws0, snr_tunables_reload (round 4) */
 
 #define SNR_OK 0
 #define SNR_ERR_NULL (-1)         /* a required pointer is NULL */
@@ -316,6 +316,23 @@ int snr_mse_pair(const float* a, const float* b, const float* target, int64_t n,
  * (1/world_size for data-parallel sums). */
 int snr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int step, float grad_scale, snr_stream_t stream);
+
+/* Adam AND the re-pack of the weights in one launch, for up to two networks (the coarse and the fine MLP of one step):
+ * replaces optimizer.step() (run_nerf.py:1611-1612) + the snr_mlp_pack the next forward would need.  The update is
+ * snr_adam_step's, bit for bit; `packed` is rewritten in place wherever it holds parameters and must have been produced by
+ * snr_mlp_pack (same cfg) once before — its zero padding is not written again.  state NULL: rate `lr` and bias corrections
+ * from `step` (1-based); else lr / bc1 / bc2_sqrt are read from the device-side snr_step_state and lr / step are ignored.
+ * Two items with the same cfg run as one launch. */
+typedef struct snr_adam_pack_item {
+  const snr_mlp_config* cfg;
+  float* params;
+  const float* grads;
+  float* exp_avg;
+  float* exp_avg_sq;
+  void* packed;
+} snr_adam_pack_item;
+int snr_adam_pack_multi(const snr_adam_pack_item* items, int n_items, float lr, float beta1, float beta2, float eps, int step,
+                        float grad_scale, const snr_step_state* state, snr_stream_t stream);
 
 /* ---- diagnostics: per-kernel HIP-event timing (used by bench.py for the roofline line) ----
  * When enabled, every kernel launch of this library is bracketed by hipEvents on its stream;

@@ -58,6 +58,10 @@ class MlpBwdItem(_c.Structure):     # snr_mlp_bwd_item
                 ("grad_params", _p), ("accumulate", _i)]
 
 
+class AdamPackItem(_c.Structure):   # snr_adam_pack_item
+    _fields_ = [("cfg", _CFG), ("params", _p), ("grads", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("packed", _p)]
+
+
 _NET, _RCFG = _c.POINTER(Net), _c.POINTER(RenderConfig)
 
 # name -> (restype, argtypes); mirrors include/spinnerf_hip.h one to one
@@ -102,6 +106,7 @@ SIGNATURES = {
     "snr_embed": (_i, [_p, _l, _i, _i, _p, _p]),
     "snr_mse_pair": (_i, [_p, _p, _p, _l, _p, _p, _p, _p]),
     "snr_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),
+    "snr_adam_pack_multi": (_i, [_c.POINTER(AdamPackItem), _i, _f, _f, _f, _f, _i, _f, _p, _p]),
     "snr_prof_enable": (_i, [_i]),
     "snr_prof_kernel_count": (_i, []),
     "snr_prof_kernel_name": (_c.c_char_p, [_i]),

@@ -22,6 +22,7 @@ SOURCES = [
     ("mlp_fwd.hip", ["-save-temps=obj"]),
     ("mlp_bwd.hip", ["-save-temps=obj"]),
     ("render_ops.hip", ["-ffp-contract=off"]),
+    ("adam_pack.hip", ["-ffp-contract=off"]),    # Adam + weight pack in one kernel: must round like render_ops' adam_kernel
     ("hashgrid.hip", ["-munsafe-fp-atomics"]),   # table gradients: hardware global_atomic_add_f32, no CAS loops
     ("prof.cpp", ["-x", "hip"]),
     ("fused.cpp", ["-x", "hip"]),                # render_rays as one call: launch order only, no kernels

@@ -430,6 +430,9 @@ __global__ __launch_bounds__(64 * kWgradWaves) void mlp_wgrad_kernel(WgradArgs a
 // the loader refills.  Reads, MFMA operand order, partial-plane layout: exactly wgrad_run's.
 // ------------------------------------------------------------------------------------------
 constexpr int kPlainWaves = 4, kPlainConsumers = 3;
+#ifndef SNR_PLAIN_AUX
+#define SNR_PLAIN_AUX 0   // cache policy of the plain jobs' DMA stream (A/B builds: 2 = non-temporal)
+#endif
 SNR_HD int plain_third(int w, int n) { return (w * n + 2) / 3; }   // first tile of consumer w of n tiles: sizes differ by <= 1
 
 // Y = tiles in flight behind the one being waited for (ring = Y + 2 slots).  Every wave issues DMA pieces — a wave's counted
@@ -478,7 +481,7 @@ __device__ __forceinline__ void plain_run4(const WgradLocal& L, char* smem, int 
     auto issue_tile = [&](int slot) {
       static_for<0, PL>([&](auto K_) {
         constexpr int k = decltype(K_)::value;
-        __builtin_amdgcn_global_load_lds(src[k], SNR_LDS(smem + slot * SLOT + (k < per_tile ? k : per_tile - 1) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src[k], SNR_LDS(smem + slot * SLOT + (k < per_tile ? k : per_tile - 1) * 1024), 16, 0, SNR_PLAIN_AUX);
       });
       if (issued + 1 < L.t1) {   // past the end the last tile is loaded again: uniform counts
         ++issued;
@@ -514,7 +517,7 @@ __device__ __forceinline__ void plain_run4(const WgradLocal& L, char* smem, int 
     static_for<0, PC>([&](auto K_) {
       constexpr int k = decltype(K_)::value;
       asm volatile("s_nop 0");   // no LDS read in the cycle in front of an LDS-DMA (mlp_device.h, Pipe::issue_one)
-      __builtin_amdgcn_global_load_lds(src[k], SNR_LDS(smem + slot * SLOT + lds_off[k]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src[k], SNR_LDS(smem + slot * SLOT + lds_off[k]), 16, 0, SNR_PLAIN_AUX);
     });
     if (issued + 1 < L.t1) {
       ++issued;

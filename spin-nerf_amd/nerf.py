@@ -165,6 +165,12 @@ class NeRF(nn.Module):
         self._packed_key = None
         self.weights_generation += 1
 
+    def note_packed_in_place(self):
+        """the parameters AND the packed blob were rewritten together through raw pointers (ops.adam_pack_step_): the blob
+        stays current, but autograd contexts that captured the old weights must notice"""
+        self.pack_generation += 1
+        self.weights_generation += 1
+
     def set_precision(self, precision):
         self.precision = precision
         self.cfg.precision = _PREC[precision]

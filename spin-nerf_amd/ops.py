@@ -538,3 +538,20 @@ def adam_step_(params, grads, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.
     check(lib.snr_adam_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), params.numel(), float(lr),
                             float(beta1), float(beta2), float(eps), int(step), float(grad_scale), stream()),
           "snr_adam_step")
+
+
+def adam_pack_step_(nets, grads, exp_avgs, exp_avg_sqs, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """Adam on the flat parameter buffers of 1..2 NeRF MLPs AND the re-pack of their weights, one launch
+    (snr_adam_pack_multi).  The networks' packed blobs are rewritten in place: the next forward needs no snr_mlp_pack."""
+    import ctypes
+    lib = _lib.load()
+    items = (_lib.AdamPackItem * len(nets))()
+    keep = []
+    for i, (net, g, m, v) in enumerate(zip(nets, grads, exp_avgs, exp_avg_sqs)):
+        packed = net.packed_weights()      # (packs once if the blob is missing or stale: its padding must exist)
+        items[i] = _lib.AdamPackItem(ctypes.pointer(net.cfg), ptr(net.flat.data), ptr(g), ptr(m), ptr(v), ptr(packed))
+        keep.append((packed, g))
+    check(lib.snr_adam_pack_multi(items, len(nets), float(lr), float(beta1), float(beta2), float(eps), int(step),
+                                  float(grad_scale), None, stream()), "snr_adam_pack_multi")
+    for net in nets:
+        net.note_packed_in_place()

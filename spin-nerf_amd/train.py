@@ -555,8 +555,17 @@ class RenderTrainer:
                 n.flat.grad = None
         self.opt_step += 1
         lr = self._lr
-        for n, m, v in zip(self.nets, self.m, self.v):
-            if n.flat.grad is None:             # torch.optim.Adam skips parameters without a gradient
+        from .nerf import NeRF
+        live = [(n, m, v) for n, m, v in zip(self.nets, self.m, self.v) if n.flat.grad is not None]   # torch.optim.Adam skips parameters without a gradient
+        fused = [t for t in live if type(t[0]) is NeRF and os.environ.get("SNR_NO_ADAM_PACK") != "1"]
+        if fused:
+            # Adam + the re-pack of the weights of both MLPs: ONE launch (csrc/adam_pack.hip) instead of two Adam and two pack launches
+            for k in range(0, len(fused), 2):
+                grp = fused[k:k + 2]
+                ops.adam_pack_step_([t[0] for t in grp], [t[0].flat.grad for t in grp], [t[1] for t in grp], [t[2] for t in grp],
+                                    lr, self.opt_step, grad_scale=1.0 / self.world_size)
+        for n, m, v in live:
+            if any(n is t[0] for t in fused):
                 continue
             ops.adam_step_(n.flat.data, n.flat.grad, m, v, lr, self.opt_step, grad_scale=1.0 / self.world_size)
             n.mark_weights_changed()   # written through a raw pointer: re-pack before the next forward

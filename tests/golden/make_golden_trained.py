@@ -56,11 +56,12 @@ def bf16_bits(t):
     return t.detach().to(torch.bfloat16).view(torch.int16).numpy().astype(np.uint16)
 
 
-def make(name, white, out_dir, n_steps=200, seed=1234):
+def make(name, white, out_dir, n_steps=200, seed=1234, noise_std=1.0, disp_loss=True):
     """Train the reference's modules on the sphere scene (white or black background), store weights + one render()."""
     H, R = import_reference()
     from oracle import nerf_oracle as O
-    torch.set_num_threads(1)          # multi-threaded reductions are order-dependent: one thread regenerates bit for bit
+    # multi-threaded reductions are order-dependent: one thread regenerates bit for bit (GOLDEN_THREADS: exploration only)
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "1")))
     torch.manual_seed(seed)           # the reference's render() draws torch.rand / torch.randn from the global stream
     np.random.seed(seed)
     nets = []
@@ -76,7 +77,7 @@ def make(name, white, out_dir, n_steps=200, seed=1234):
         return R.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=65536)
 
     kw = dict(network_query_fn=network_query_fn, perturb=1.0, N_importance=64, network_fine=net_f, N_samples=64,
-              network_fn=net_c, use_viewdirs=True, white_bkgd=bool(white), raw_noise_std=1.0, ndc=False, near=NEAR, far=FAR,
+              network_fn=net_c, use_viewdirs=True, white_bkgd=bool(white), raw_noise_std=noise_std, ndc=False, near=NEAR, far=FAR,
               lindisp=False)
     rays_all, tgt_all = [], []
     for k in range(6):
@@ -122,10 +123,12 @@ def make(name, white, out_dir, n_steps=200, seed=1234):
         p.grad = None
     rgb, disp, acc, depth, extras = R.render(Hh, Ww, FOCAL, chunk=20, rays=rays, retraw=True, pytest=True, **kw_fix)
     target = tgt_all[sel]
-    loss = H.img2mse(rgb, target) + H.img2mse(extras['rgb0'], target) + 0.1 * H.img2mse(disp, torch.zeros_like(disp))
+    loss = H.img2mse(rgb, target) + H.img2mse(extras['rgb0'], target)
+    if disp_loss:   # (a ray that hits nothing has acc = 0 and disp = 1 / (0 / 0) = NaN in the reference: no disparity term then)
+        loss = loss + 0.1 * H.img2mse(disp, torch.zeros_like(disp))
     loss.backward()
-    arrs.update(H=Hh, W=Ww, focal=FOCAL, rays=rays, ndc=0, lindisp=0, Nf=128, vd=1, perturb=1.0, noise_std=1.0,
-                white=int(bool(white)), near=NEAR, far=FAR, detach=0, use_c2w=0, need_alpha=0, och=4, chunk=20, rgb=rgb,
+    arrs.update(H=Hh, W=Ww, focal=FOCAL, rays=rays, ndc=0, lindisp=0, Nf=128, vd=1, perturb=1.0, noise_std=noise_std,
+                white=int(bool(white)), disp_loss=int(bool(disp_loss)), near=NEAR, far=FAR, detach=0, use_c2w=0, need_alpha=0, och=4, chunk=20, rgb=rgb,
                 disp=disp, acc=acc, depth=depth, target=target, loss=loss, train_psnr_last20=float(np.mean(psnr[-20:])),
                 train_steps=n_steps, torch_seed=seed)
     for k, v in extras.items():
@@ -143,7 +146,8 @@ def make(name, white, out_dir, n_steps=200, seed=1234):
           f"with acc < 0.5: {int((acc < 0.5).sum())}")
 
 
-CASES = (("render_trained_fine_vd", True), ("render_trained_black_vd", False))
+# name, white background, raw_noise_std (training and fixture render), disparity term in the fixture's loss
+CASES = (("render_trained_fine_vd", True, 1.0, True), ("render_trained_black_vd", False, 0.0, False))
 
 
 def main():
@@ -153,10 +157,10 @@ def main():
     if check:
         import tempfile
         out_dir = tempfile.mkdtemp(prefix="golden_trained_")
-    for name, white in CASES:
+    for name, white, noise_std, disp_loss in CASES:
         if only and name not in only:
             continue
-        make(name, white, out_dir)
+        make(name, white, out_dir, noise_std=noise_std, disp_loss=disp_loss)
         if check:
             a, b = np.load(os.path.join(out_dir, name + ".npz")), np.load(os.path.join(HERE, name + ".npz"))
             assert set(a.files) == set(b.files), (name, set(a.files) ^ set(b.files))

@@ -48,8 +48,22 @@ def render_case_nets(g):
 
 RENDER_CASES = ["render_ndc_fine_vd", "render_lindisp_fine_vd", "render_lindisp_fine_vd_detach",
                 "render_ndc_coarse_vd", "render_noperturb_fine_vd_alpha", "render_ndc_fine_novd",
-                "render_c2w_fine_vd", "render_trained_fine_vd"]
-TRAINED_CASES = ["render_trained_fine_vd"]
+                "render_c2w_fine_vd", "render_trained_fine_vd", "render_trained_black_vd"]
+# networks the REFERENCE trained (tests/golden/make_golden_trained.py, seeded and regenerable): the sphere in front of a white
+# background with density noise (every ray ends opaque: acc == 1), and in front of a black one without noise (rays that miss
+# or graze the sphere: acc in [0, 1), 28 of 48 rays below 0.99)
+TRAINED_CASES = ["render_trained_fine_vd", "render_trained_black_vd"]
+
+
+def fixture_loss(g, mse, rgb, rgb0, disp):
+    """the loss the fixture's gradients belong to: img2mse(rgb) [+ img2mse(rgb0)] + 0.1 img2mse(disp, 0) — without the
+    disparity term where the fixture says so (a ray that hits nothing has disp = 1 / (0 / 0) = NaN in the reference)"""
+    loss = mse(rgb)
+    if rgb0 is not None:
+        loss = loss + mse(rgb0)
+    if int(g.get("disp_loss", 1)):
+        loss = loss + 0.1 * (disp ** 2).mean()
+    return loss
 R2O_CASES = ["r2o_s64", "r2o_s192_white_noise", "r2o_s192_detach", "r2o_s64_zero_sigma",
              "r2o_s64_huge_sigma", "r2o_s5"]
 PDF_CASES = ["pdf_rand", "pdf_det", "pdf_delta", "pdf_delta_det", "pdf_uniform", "pdf_zeros", "pdf_small"]

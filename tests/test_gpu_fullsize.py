@@ -125,6 +125,89 @@ def test_split_gradient_equals_whole(S, precision, gate):
     assert rel < gate, rel
 
 
+def _oracle_bf16_grads(sd, pts, dirs, d_raw):
+    """autograd through the oracle's bf16-rounding emulation (DS_NeRF/run_nerf_helpers.py:104-127 with the kernels' rounding
+    points) on the CPU: 196 608 samples take ~10 s on the test box's cores"""
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    for v in sd.values():
+        v.requires_grad_(True)
+        v.grad = None
+    ref = O.run_network(sd, pts.cpu(), dirs.cpu(), use_viewdirs=True, mlp=O.nerf_forward_bf16emu)
+    (ref * d_raw.cpu()).sum().backward()
+    return {k: v.grad for k, v in sd.items()}
+
+
+def _assert_grads_close(net, ref, gate, what):
+    got = net.named_views(net.flat.grad)
+    worst = 0.0
+    for k, g in ref.items():
+        if g is None:
+            continue
+        a, b = got[k].detach().cpu().double().reshape(-1), g.double().reshape(-1)
+        rel = float((a - b).norm() / b.norm())
+        worst = max(worst, rel)
+        assert rel < gate, f"{what}: {k}: relative L2 error vs the oracle's bf16 emulation {rel:.2e}"
+    return worst
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n_s", [N_C + N_F, N_C])
+def test_bench_size_bf16_backward_matches_the_oracle(S, n_s):
+    """the weight-gradient launch AT THE BENCH'S SIZE — 1024 rays x 192 samples (6144 tiles: the
+    real slot apportionment, pacing and plain-workgroup shares of mlp_wgrad_pair.h) and the coarse 1024 x 64 launch —
+    compared per parameter tensor with autograd through the oracle's bf16 emulation: relative L2 <= 5e-2, the gate of the
+    small-size tests (tests/test_gpu_kernels.py: test_mlp_backward_bf16)."""
+    sd, net = _net(S, 21)
+    pts, dirs = _inputs(31, N_RAYS, n_s)
+    # (+ 0.25: a zero-mean d raw makes the bias gradients — plain sums of the incoming gradients — cancel to ~sqrt(N), and the
+    #  relative error of such a sum measures the draw, not the kernel)
+    d = (torch.randn(N_RAYS, n_s, 4, generator=torch.Generator().manual_seed(32)) + 0.25).cuda()
+    ref = _oracle_bf16_grads(sd, pts, dirs, d)
+    _grad(net, pts, dirs, d)
+    assert torch.isfinite(net.flat.grad).all()
+    _assert_grads_close(net, ref, 5e-2, f"1024 x {n_s}")
+
+
+@pytest.mark.timeout(900)
+def test_bench_size_merged_backward_of_both_networks_matches_the_oracle(S):
+    """The training step's real launch sequence: coarse (1024 x 64) and fine (1024 x 192) backward passes as ONE
+    snr_mlp_backward_multi call — one chain launch, one weight-gradient launch (both networks' layer pairs on the pair slots,
+    their plain jobs on the plain workgroups), one reduce — against the oracle's bf16 emulation per network and tensor
+    (5e-2), and against the same two passes run one network at a time (a different split of the samples over the
+    workgroups: bf16 partial sums, 6e-3 of the norm)."""
+    ops = S.ops
+    sd_f, net_f = _net(S, 22)
+    sd_c, net_c = _net(S, 23)
+    pts_f, dirs = _inputs(33, N_RAYS, N_C + N_F)
+    pts_c = pts_f[:, :N_C].contiguous()
+    g = torch.Generator().manual_seed(34)
+    d_f = (torch.randn(N_RAYS, N_C + N_F, 4, generator=g) + 0.25).cuda()   # (non-zero mean: see the test above)
+    d_c = (torch.randn(N_RAYS, N_C, 4, generator=g) + 0.25).cuda()
+    L = S._lib
+    lib = L.load()
+
+    def fwd(net, pts):
+        n = pts.shape[0] * pts.shape[1]
+        raw = torch.empty(n, 4, device="cuda")
+        act = torch.empty(lib.snr_mlp_act_bytes(net.cfg, n), dtype=torch.uint8, device="cuda")
+        packed = net.packed_weights()
+        L.check(lib.snr_mlp_forward(net.cfg, L.ptr(packed), L.ptr(pts.reshape(-1, 3).contiguous()), None, 0, None, L.ptr(dirs), 3, n,
+                                    pts.shape[1], L.ptr(raw), L.ptr(act), L.stream()), "snr_mlp_forward")
+        return (packed, act, n)
+    sv_f, sv_c = fwd(net_f, pts_f), fwd(net_c, pts_c)
+    g_f, g_c = ops.mlp_train_backward_multi([net_f, net_c], [sv_f, sv_c], [d_f.reshape(-1, 4), d_c.reshape(-1, 4)])
+    one_f = ops.mlp_train_backward(net_f, sv_f, d_f.reshape(-1, 4))
+    one_c = ops.mlp_train_backward(net_c, sv_c, d_c.reshape(-1, 4))
+    torch.cuda.synchronize()
+    assert torch.isfinite(g_f).all() and torch.isfinite(g_c).all()
+    for merged, single in ((g_f, one_f), (g_c, one_c)):
+        assert float((merged - single).norm() / single.norm()) < 6e-3
+    for net, sd, pts, d, grad, what in ((net_f, sd_f, pts_f, d_f, g_f, "fine"), (net_c, sd_c, pts_c, d_c, g_c, "coarse")):
+        ref = _oracle_bf16_grads(sd, pts, dirs, d)
+        net.flat.grad = grad
+        _assert_grads_close(net, ref, 5e-2, what + " network of the merged launch")
+
+
 def test_training_step_at_bench_size(S):
     import argparse, contextlib, io, tempfile
     RenderTrainer = importlib.import_module("spin-nerf_amd.train").RenderTrainer

@@ -219,6 +219,38 @@ def test_adam_matches_torch_adam(S):
     close(p, p_ref, atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("vd", [True, False])
+def test_adam_and_weight_pack_in_one_launch(S, vd, precision):
+    """snr_adam_pack_multi (csrc/adam_pack.hip): Adam on both networks' flat buffers AND the re-pack of their weights as one
+    launch.  Against the two-kernel route on clones of the same buffers, three steps with random gradients: parameters and
+    both moments bit-identical to snr_adam_step; the packed blobs (forward fragments, transposed fragments, bias block,
+    every padding byte) bit-identical to snr_mlp_pack of the updated parameters."""
+    L = S._lib
+    lib = L.load()
+    out_ch = 4 if vd else 5
+    nets = [make_net(S, O.make_wild_params(seed=31 + k, use_viewdirs=vd, output_ch=out_ch, input_ch_views=27 if vd else 0), vd,
+                     precision, out_ch=out_ch) for k in range(2)]
+    g = torch.Generator().manual_seed(5)
+    n = nets[0].flat.numel()
+    ms = [torch.rand(n, generator=g).cuda() * 1e-3 for _ in nets]
+    vs = [torch.rand(n, generator=g).cuda() * 1e-6 for _ in nets]
+    ref = [(net.flat.data.clone(), m.clone(), v.clone()) for net, m, v in zip(nets, ms, vs)]
+    for net in nets:
+        net.packed_weights()
+    for step in range(1, 4):
+        grads = [(torch.randn(n, generator=g) * (10.0 ** -step)).cuda() for _ in nets]
+        S.ops.adam_pack_step_(nets, grads, ms, vs, 5e-4, step, grad_scale=0.5)
+        for (p, m, v), gr in zip(ref, grads):
+            S.adam_step_(p, gr, m, v, 5e-4, step, grad_scale=0.5)
+        for net, m, v, (p_r, m_r, v_r) in zip(nets, ms, vs, ref):
+            assert torch.equal(net.flat.data, p_r) and torch.equal(m, m_r) and torch.equal(v, v_r), step
+            blob = net.packed_weights()          # (current: no re-pack happens here)
+            want = torch.empty_like(blob)
+            L.check(lib.snr_mlp_pack(net.cfg, L.ptr(p_r), L.ptr(want), L.stream()), "snr_mlp_pack")
+            assert torch.equal(blob, want), f"packed blob differs after step {step}"
+
+
 # ---------------------------------------------------------------------------------------------
 # MLP backward: d loss / d params against autograd through the oracle MLP
 # ---------------------------------------------------------------------------------------------

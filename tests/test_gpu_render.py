@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load, T, render_case_nets, chunked_pytest_randoms, RENDER_CASES
+from helpers import load, T, render_case_nets, chunked_pytest_randoms, fixture_loss, RENDER_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -311,10 +311,7 @@ def test_render_backward_matches_reference_grads(S, name):
     net_c, net_f, kw = build(S, g)
     rgb, disp, acc, depth, extras = run(S, g, kw, True)
     target = T(g["target"]).cuda()
-    loss = S.img2mse(rgb, target)
-    if "rgb0" in extras:
-        loss = loss + S.img2mse(extras["rgb0"], target)
-    loss = loss + 0.1 * S.img2mse(disp, torch.zeros_like(disp))
+    loss = fixture_loss(g, lambda x: S.img2mse(x, target), rgb, extras.get("rgb0"), disp)
     close(loss, g["loss"], rtol=2e-3)
     loss.backward()
     fine = int(g["Nf"]) > 0
@@ -422,28 +419,37 @@ def test_embedder_call_matches_reference_embedding(S):
     assert d == 3 and torch.equal(e(x), x)
 
 
-# ---- the benched dtype on networks the REFERENCE trained (tests/golden/make_golden_trained.py; VERDICT r02 item 3a) ----
-# 200 Adam steps of the reference's own modules on the analytic sphere: raw reaches 39 (colour) / 48 (density), every ray is
-# opaque.  Measured on MI355X (tests/probes/trained_diag.py), gates = 2x: coarse rgb0 2.6e-3, free-running rgb 1.5e-3, raw
-# 0.11 = 0.3 % of its range, weights 1.3e-3, depth 2.7e-4, relative disparity 1.2e-4, loss 1.1e-3 relative, parameter
-# gradients 2.4e-2 (coarse network) / 3.5e-2 (fine network) relative L2 — SURVEY.md §7(b) expected rgb ~3e-3, raw ~1e-2.
-# (fp32 mode on the same fixture: rgb 8e-7, raw 2e-5, gradients 6e-7 / 1.4e-4 — held by the generic tests above.)
-BF16_TRAINED = dict(rgb=3e-3, acc=1e-5, raw_frac=6e-3, weights=3e-3, depth=6e-4, disp_rtol=3e-4, loss_rtol=2.5e-3,
-                    grad_coarse=5e-2, grad_fine=7e-2)
+# ---- the benched dtype on networks the REFERENCE trained (tests/golden/make_golden_trained.py; VERDICT r02 item 3a, r03 4b/4d) ----
+# 200 Adam steps of the reference's own modules on the analytic sphere, seeded and regenerable (`--check`).  Gates = 2x what
+# tests/probes/trained_diag.py measures on MI355X with the regenerated fixtures:
+#   white background + density noise (raw up to 41 / 52; every ray opaque, acc == 1): coarse rgb0 3.4e-3, free-running rgb
+#     1.3e-3, raw 0.11 = 0.27 % of its range, weights 8.9e-4, depth 1.7e-4, relative disparity 7.7e-5, loss 6.6e-4 relative,
+#     parameter gradients 3.2e-2 (coarse) / 8.6e-3 (fine) relative L2 — SURVEY.md §7(b) expected rgb ~3e-3, raw ~1e-2;
+#   black background, no noise (acc from 0.006 to 0.997: 28 of 48 rays below 0.99, 10 below 0.5 — the semi-transparent and
+#     empty rays the white scene never produces): coarse rgb0 1.2e-3, acc0 1.6e-3, free-running rgb 5.8e-3, acc 6.4e-3, raw
+#     0.15 = 0.34 %, weights 2.8e-3, depth 1.1e-2, relative disparity 1.1e-3, loss 7.7e-3, gradients 2.8e-2 / 0.11 (a ray that
+#     is not opaque passes every bf16 rounding of its densities on to the transmittance of all samples behind).
+# (fp32 mode on the same fixtures: rgb 2e-6, raw 2e-5, gradients 1.5e-5 / 7e-3 — held by the generic tests above.)
+BF16_TRAINED_GATES = {
+    "render_trained_fine_vd": dict(rgb=3e-3, rgb0=7e-3, acc=1e-5, raw_frac=6e-3, weights=3e-3, depth=6e-4, disp_rtol=3e-4,
+                                   loss_rtol=2.5e-3, grad_coarse=6.5e-2, grad_fine=7e-2),
+    "render_trained_black_vd": dict(rgb=1.2e-2, rgb0=2.5e-3, acc=1.3e-2, raw_frac=7e-3, weights=6e-3, depth=2.2e-2, disp_rtol=2.5e-3,
+                                    loss_rtol=1.6e-2, grad_coarse=6e-2, grad_fine=0.22),
+}
 
 
 def test_render_bf16_on_reference_trained_networks(S):
     from helpers import TRAINED_CASES
     for name in TRAINED_CASES:
         g = load(name)
-        G = BF16_TRAINED
+        G = BF16_TRAINED_GATES[name]
         net_c, net_f, kw = build(S, g, "bf16")
         with torch.no_grad():
             rgb, disp, acc, depth, ex = run(S, g, kw, True)
         n = g["rgb"].reshape(-1, 3).shape[0]
         # the whole free-running pipeline: trained networks put their probability mass in few bins, resampling is
         # well-conditioned there and the maps can be held directly
-        close(ex["rgb0"], g["x_rgb0"], atol=2 * G["rgb"], rtol=0, msg="rgb0")
+        close(ex["rgb0"], g["x_rgb0"], atol=G["rgb0"], rtol=0, msg="rgb0")
         close(ex["acc0"], g["x_acc0"], atol=G["acc"], rtol=0, msg="acc0")
         close(rgb, g["rgb"], atol=G["rgb"], rtol=0, msg="rgb")
         close(acc, g["acc"], atol=G["acc"], rtol=0, msg="acc")
@@ -456,8 +462,9 @@ def test_render_bf16_on_reference_trained_networks(S):
         close(raw, ref_raw, atol=G["raw_frac"] * float(np.abs(ref_raw).max()), rtol=0, msg="raw")
         rnd = chunked_pytest_randoms(n, int(g["chunk"]), 64, int(g["Nf"]), float(g["perturb"]), float(g["noise_std"]))
         with torch.no_grad():
-            r2, d2, a2, w2, dp2, _ = S.raw2outputs(raw, z, rays[:, 3:6], white_bkgd=bool(g["white"]), noise=rnd["noise_f"].cuda(),
-                                                   rays=rays)
+            r2, d2, a2, w2, dp2, _ = S.raw2outputs(raw, z, rays[:, 3:6], white_bkgd=bool(g["white"]),
+                                                   noise=rnd["noise_f"].cuda() if rnd["noise_f"] is not None else None, rays=rays)
+        close(a2, g["acc"].reshape(n), atol=G["acc"], rtol=0, msg="acc (teacher-forced)")
         close(r2, g["rgb"].reshape(n, 3), atol=G["rgb"], rtol=0, msg="rgb (teacher-forced)")
         close(w2, g["x_weights"].reshape(n, -1), atol=G["weights"], rtol=0, msg="weights")
         close(dp2, g["depth"].reshape(n), atol=G["depth"], rtol=0, msg="depth")
@@ -470,13 +477,14 @@ def test_render_bf16_parameter_gradients_on_reference_trained_networks(S):
     from helpers import TRAINED_CASES
     for name in TRAINED_CASES:
         g = load(name)
+        G = BF16_TRAINED_GATES[name]
         net_c, net_f, kw = build(S, g, "bf16")
         rgb, disp, acc, depth, extras = run(S, g, kw, True)
         target = T(g["target"]).cuda()
-        loss = S.img2mse(rgb, target) + S.img2mse(extras["rgb0"], target) + 0.1 * S.img2mse(disp, torch.zeros_like(disp))
-        close(loss, g["loss"], rtol=BF16_TRAINED["loss_rtol"], atol=0)
+        loss = fixture_loss(g, lambda x: S.img2mse(x, target), rgb, extras["rgb0"], disp)
+        close(loss, g["loss"], rtol=G["loss_rtol"], atol=0)
         loss.backward()
-        for pfx, net, gate in (("gc_", net_c, BF16_TRAINED["grad_coarse"]), ("gf_", net_f, BF16_TRAINED["grad_fine"])):
+        for pfx, net, gate in (("gc_", net_c, G["grad_coarse"]), ("gf_", net_f, G["grad_fine"])):
             for k, gr in net.named_views(net.flat.grad).items():
                 if pfx + k not in g:
                     assert float(gr.abs().max()) == 0.0, k

@@ -326,7 +326,16 @@ def test_one_network_for_both_passes_fused_vs_per_kernel(monkeypatch):
     assert rel < 1e-5, rel
 
 
-def test_bf16_trainer_step_matches_the_oracle_with_bf16_rounding_emulation():
+# gates = ~4x the values measured on MI355X with the seeded fixtures (tests/probes/r04_trainer_bf16_diag.py, three draw seeds):
+#   white-background fixture (every ray opaque):      loss 3e-5 .. 2.8e-4 relative, rgb 1.4e-4 .. 3.7e-4, first moments 2.7e-3 .. 6.4e-3 / 1.9e-3 .. 2.4e-3
+#   black-background fixture (acc in [0.006, 0.997]): loss 2e-4 .. 2.6e-3, rgb 4e-4 .. 6.5e-3, first moments 2.7e-3 .. 3.2e-3 / 4e-3 .. 4.3e-2
+#   (semi-transparent rays: a sample displaced by the bf16 network's slightly different pdf moves colour AND opacity)
+TRAINER_BF16_GATES = {"render_trained_fine_vd": dict(loss=1e-3, rgb=1.5e-3, m=(2.5e-2, 1e-2), cos=0.995),
+                      "render_trained_black_vd": dict(loss=1e-2, rgb=2.5e-2, m=(1.2e-2, 0.17), cos=0.97)}
+
+
+@pytest.mark.parametrize("name", ["render_trained_fine_vd", "render_trained_black_vd"])
+def test_bf16_trainer_step_matches_the_oracle_with_bf16_rounding_emulation(name):
     """The benched dtype through RenderTrainer.step — the code bench.py times — against O.train_step run with the oracle's
     bf16 emulation of the MLP (same rounding points: weights, encodings and every activation to bf16, fp32 accumulation;
     DS_NeRF/run_nerf.py:1482-1490, 1611-1622), injected draws, on the networks the reference trained
@@ -336,7 +345,9 @@ def test_bf16_trainer_step_matches_the_oracle_with_bf16_rounding_emulation():
     import spin_nerf_amd as S
     from helpers import load, render_case_nets
     train = importlib.import_module("spin-nerf_amd.train")
-    g = load("render_trained_fine_vd")
+    g = load(name)
+    G = TRAINER_BF16_GATES[name]
+    white, std = bool(g["white"]), float(g["noise_std"])
     sd_c, sd_f = render_case_nets(g)
     H, W, focal, near, far = int(g["H"]), int(g["W"]), float(g["focal"]), float(g["near"]), float(g["far"])
     Nc, Nf = 64, 128
@@ -354,29 +365,27 @@ def test_bf16_trainer_step_matches_the_oracle_with_bf16_rounding_emulation():
         return S.run_network(inputs, viewdirs, network_fn)
     q._snr_fused = True
     kw = dict(network_query_fn=q, perturb=1.0, N_importance=Nf, network_fine=net_f, N_samples=Nc, network_fn=net_c,
-              use_viewdirs=True, white_bkgd=True, raw_noise_std=1.0, ndc=False, lindisp=False, near=near, far=far)
+              use_viewdirs=True, white_bkgd=white, raw_noise_std=std, ndc=False, lindisp=False, near=near, far=far)
     tr = train.RenderTrainer(kw, lrate=5e-4, lrate_decay=250)
     pc = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
     pf = {k: v.clone().requires_grad_(True) for k, v in sd_f.items()}
     opt = O.AdamState(list(pc.values()) + list(pf.values()), lr=5e-4)
     okw = dict(H=H, W=W, focal=focal, chunk=1024 * 32, ndc=False, near=near, far=far, use_viewdirs=True, N_samples=Nc,
-               N_importance=Nf, perturb=1.0, white_bkgd=True, lindisp=False, mlp=O.nerf_forward_bf16emu)
+               N_importance=Nf, perturb=1.0, white_bkgd=white, lindisp=False, mlp=O.nerf_forward_bf16emu)
     gen = torch.Generator().manual_seed(9)
     rnd = dict(t_rand=torch.rand(N, Nc, generator=gen), u=torch.rand(N, Nf, generator=gen),
-               noise_c=torch.randn(N, Nc, generator=gen), noise_f=torch.randn(N, Nc + Nf, generator=gen))
+               noise_c=torch.randn(N, Nc, generator=gen) * std, noise_f=torch.randn(N, Nc + Nf, generator=gen) * std)
     p0 = [torch.cat([v.detach().reshape(-1) for v in p.values()]).clone() for p in (pc, pf)]
     ref_loss, ref_rgb = O.train_step(pc, pf, opt, rays, target, okw, randoms=rnd)
     loss, rgb = tr.step(H, W, focal, rays.cuda(), target.cuda(), randoms={k: v.cuda() for k, v in rnd.items()})
-    # measured on MI355X: loss 1.6e-5 relative, rgb 3.8e-4, first moments 2.6e-3 (coarse) / 2.1e-3 (fine) relative L2, update
-    # cosine 1.0000; gates = 4x
-    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss)), (float(loss), float(ref_loss))
-    assert float((rgb.cpu() - ref_rgb).abs().max()) < 1.5e-3
+    assert abs(float(loss) - float(ref_loss)) < G["loss"] * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    assert float((rgb.cpu() - ref_rgb).abs().max()) < G["rgb"]
     n_c = sum(v.numel() for v in pc.values())
     for i, (net, m, params) in enumerate(zip((net_c, net_f), tr.m, (pc, pf))):
         ref_m = torch.cat([mm.reshape(-1) for mm in (opt.m[:len(pc)] if i == 0 else opt.m[len(pc):])])
         rel = float((m.cpu() - ref_m).norm() / ref_m.norm())
-        assert rel < 1e-2, f"network {i}: first moment (= 0.1 x gradient) off by {rel:.3e} relative L2"
+        assert rel < G["m"][i], f"network {i}: first moment (= 0.1 x gradient) off by {rel:.3e} relative L2"
         upd = net.flat.detach().cpu() - p0[i]
         ref_upd = torch.cat([v.detach().reshape(-1) for v in params.values()]) - p0[i]
         cos = float((upd @ ref_upd) / (upd.norm() * ref_upd.norm()))
-        assert cos > 0.995, f"network {i}: update cosine {cos:.4f}"
+        assert cos > G["cos"], f"network {i}: update cosine {cos:.4f}"

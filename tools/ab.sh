@@ -6,7 +6,7 @@ mkdir -p $OUT
 for rep in 1 2; do
   for v in "$@"; do
     if [ "$v" = base ]; then unset SNR_LIB; else export SNR_LIB=$PWD/spin-nerf_amd/lib/ablate/libspinnerf_hip_$v.so; fi
-    python bench.py --no-cpu-baseline --no-hashgrid > $OUT/${v}_$rep.log 2>&1
+    python bench.py --no-cpu-baseline --no-hashgrid ${AB_ARGS:-} > $OUT/${v}_$rep.log 2>&1
   done
 done
 python - "$OUT" "$@" <<'PY'
@@ -17,5 +17,7 @@ for v in sys.argv[2:]:
         for l in open(f):
             if l.startswith("{"):
                 d = json.loads(l); k = d["kernels"]
-                print(f"{v:10s} step {d['ms_per_step']:.4f} ms  frame {d.get('ms_per_frame_378x504') or 0:.2f} ms  fwd {k['mlp_fwd']['ms_per_step']:.4f} dgrad {k['mlp_dgrad']['ms_per_step']:.4f} wgrad {k['mlp_wgrad']['ms_per_step']:.4f}")
+                g = lambda n: k.get(n, {}).get("ms_per_step", 0.0)
+                print(f"{v:10s} step {d['ms_per_step']:.4f} ms  frame {d.get('ms_per_frame_378x504') or 0:.2f} ms  fwd {g('mlp_fwd'):.4f} dgrad {g('mlp_dgrad'):.4f} "
+                      f"wgrad_pair {g('mlp_wgrad_pair'):.4f} wgrad {g('mlp_wgrad'):.4f} reduce {g('mlp_wgrad_reduce'):.4f} pack {g('mlp_pack'):.4f} adam {g('adam'):.4f}")
 PY
