@@ -388,9 +388,12 @@ def main():
     n_c, n_f = ns.n_rand * ns.n_coarse, ns.n_rand * (ns.n_coarse + ns.n_fine)
     evals_per_step = n_c + (n_f if ns.n_fine else 0)
     recompute = "mlp_wgrad_pair" in prof
+    # round 4: the plain split-K jobs (skip layer's encoding columns, head) run INSIDE the layer-pair launch, on their own
+    # workgroups: one weight-gradient launch per step covers every weight of both networks
+    merged_wgrad = recompute and "mlp_wgrad" not in prof
     flops = {"mlp_fwd": 2 * MAC_FWD, "mlp_dgrad": 2 * MAC_DGRAD, "mlp_wgrad": 2 * (MAC_WGRAD_REST if recompute else MAC_WGRAD)}
     if recompute:
-        flops["mlp_wgrad_pair"] = 2 * MAC_WGRAD_PAIR
+        flops["mlp_wgrad_pair"] = 2 * (MAC_WGRAD if merged_wgrad else MAC_WGRAD_PAIR)
     kernels = {}
     for k, (ms, cnt) in prof.items():
         kernels[k] = {"ms_per_step": ms / ns.steps, "launches_per_step": cnt / ns.steps}
@@ -416,8 +419,16 @@ def main():
             e = pk.get(name + "_kernel")
             return None if e is None else (2 * e.get("FETCH_SIZE_KiB_per_launch", 0.0) + e.get("WRITE_SIZE_KiB_per_launch", 0.0)) * 1024
         traffic = launch_bytes(dom)
-        per = [(launch_bytes(k), kernels[k]["launches_per_step"]) for k in kernels if launch_bytes(k) is not None]
-        hbm_step = sum(b * n for b, n in per) if per else None
+        # bytes per step: every library kernel of the profiled command (2 x FETCH + WRITE per launch x its launches), divided by
+        # the command's steps — counted through the dominant kernel, whose launches per step are known
+        dom_n = pk.get(dom + "_kernel", {}).get("FETCH_SIZE_launches")
+        if dom_n:
+            steps_prof = dom_n / launches
+            hbm_step = sum((2 * e.get("FETCH_SIZE_KiB_per_launch", 0.0) * e.get("FETCH_SIZE_launches", 0)
+                            + e.get("WRITE_SIZE_KiB_per_launch", 0.0) * e.get("WRITE_SIZE_launches", 0)) * 1024 for e in pk.values()) / steps_prof
+        else:   # (PMC files of earlier rounds: per-launch averages only)
+            per = [(launch_bytes(k), kernels[k]["launches_per_step"]) for k in kernels if launch_bytes(k) is not None]
+            hbm_step = sum(b * n for b, n in per) if per else None
     roofline = {
         "kernel": dom, "bound": "mfma",
         "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kernels[dom]["tflops"] / peak,
@@ -437,17 +448,20 @@ def main():
         if recompute:
             # odd layers only (mlp_wgrad_pair.h): forward h1,h3,h5,h7; dgrad d z1,3,5,7; the pair kernel fetches each pair's two
             # tensors + 32 B of flags ONCE from HBM (its two kinds of workgroup share the fetch through L2)
+            plain_bytes = 2 * ((256 + 64) + (128 + 16 + 256 + 32) + (16 + 128))
             stream_bytes = {"mlp_fwd": 2 * (64 + 4 * 256 + 32 + 128) + 9 * 32,
                             "mlp_dgrad": 2 * (16 + 4 * 256 + 128) + 9 * 32,
-                            "mlp_wgrad_pair": 2 * (64 + 256) + 32 + 3 * (2 * 512 + 32),
-                            "mlp_wgrad": 2 * ((256 + 64) + (128 + 16 + 256 + 32) + (16 + 128))}
+                            "mlp_wgrad_pair": 2 * (64 + 256) + 32 + 3 * (2 * 512 + 32) + (plain_bytes if merged_wgrad else 0),
+                            "mlp_wgrad": plain_bytes}
         for k, b in stream_bytes.items():
             if k in kernels:
                 gbps = b * evals_per_step / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
                 kernels[k]["stream_GBps"] = gbps
         if recompute and dom == "mlp_wgrad_pair":
             # the kernel executes about twice its algorithmic MFMAs (it rebuilds h_2k and d z_2k): matrix-pipe time it cannot avoid
-            mf = (320 + 512 + 512 + 512) * 32768 / 32          # MFMA FLOPs per sample: 1856 MFMAs per 32-sample tile (mlp_wgrad_pair.h)
+            # MFMA FLOPs per sample: 1856 MFMAs per 32-sample tile in the layer pairs (mlp_wgrad_pair.h) + the plain jobs' 138
+            # (mlp_wgrad.h: plain_run4 — 130 algorithmic, 8 on duplicate tiles that keep its body branch-free)
+            mf = (320 + 512 + 512 + 512 + (138 if merged_wgrad else 0)) * 32768 / 32
             roofline["mfma_executed"] = {"flops_per_launch": mf * evals_per_step / launches,
                                          "achieved": mf * evals_per_step / (kernels[dom]["ms_per_step"] * 1e-3) / 1e12,
                                          "frac": mf * evals_per_step / (kernels[dom]["ms_per_step"] * 1e-3) / 1e12 / peak,
@@ -483,7 +497,10 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
         "ms_per_step_profiled": prof_elapsed / ns.steps * 1e3,
-        "step_route": "captured HIP graph replay (SNR_STEP_GRAPH=1)" if graph_route else "two fused library calls + Adam per step",
+        "step_route": "captured HIP graph replay (SNR_STEP_GRAPH=1)" if graph_route else
+                      "library calls per step: step_prepare, render_rays_fused_forward, render_rays_fused_backward (both networks' "
+                      "backward as one launch sequence), adam_pack_multi",
+        "launches_per_step": sum(v["launches_per_step"] for v in kernels.values()) + (1 if "mlp_wgrad_reduce" in kernels else 0),
     }
     if dist_info is not None:
         out["distributed"] = dist_info

@@ -28,7 +28,8 @@ extern "C" {
 #endif
 
 #define SNR_ABI_VERSION 3   /* 2: snr_mlp_backward / snr_pack_rays argument lists, snr_net / snr_step_state (round 2)
-                             * 3: snr_mlp_backward_multi, snr_adam_pack_multi, snr_render_ws_layout.bwd_ws0, snr_tunables_reload (round 4) */
+                             * 3: snr_mlp_backward_multi, snr_adam_pack_multi, snr_render_step_prepare, snr_render_config.flags,
+                             *    snr_render_ws_layout.bwd_ws0, snr_tunables_reload (round 4) */
 
 #define SNR_OK 0
 #define SNR_ERR_NULL (-1)         /* a required pointer is NULL */
@@ -246,7 +247,10 @@ typedef struct snr_render_config {
   int white_bkgd;        /* --white_bkgd */
   int perturb;           /* perturb > 0: stratified / hierarchical draws are random */
   float raw_noise_std;   /* --raw_noise_std */
+  int flags;             /* SNR_RENDER_* */
 } snr_render_config;
+#define SNR_RENDER_Z_COARSE_READY 1  /* the workspace already holds the stratified z_vals of the coarse samples
+                                        (snr_render_step_prepare wrote them): the forward does not sample them again */
 /* byte offsets inside the workspace of the tensors render_rays returns in its dict (run_nerf.py:715-726) and of the
  * intermediates the backward consumes; -1 = absent in this configuration */
 typedef struct snr_render_ws_layout {
@@ -273,6 +277,16 @@ int snr_render_rays_fused_forward(const snr_render_config* cfg, const snr_net* c
                                   const uint64_t* offset_base, const float* target, int64_t n_rays_global, void* ws, float* rgb_map, float* disp_map,
                                   float* acc_map, float* depth_map, float* rgb0, float* disp0, float* acc0, float* z_std,
                                   float* loss, snr_stream_t stream);
+/* The head of a training step as ONE launch (pack_rays + stratified sampling + the zero fill of the loss accumulator were
+ * three): the packed ray rows of render(rays=...)'s plain case (run_nerf.py:117-153: no c2w_staticcam, scalar near / far, no
+ * depth column), the stratified z_vals of the coarse samples (run_nerf.py:646-668; t_rand [n, n_samples] when non-NULL, else
+ * the Philox draws of offset + 1 like the fused forward when cfg->perturb) written to `z_coarse` = the forward's workspace +
+ * snr_render_ws_layout.z_coarse, and loss[0] = loss[1] = 0.  The forward that follows is called with
+ * SNR_RENDER_Z_COARSE_READY set in cfg->flags. */
+int snr_render_step_prepare(const snr_render_config* cfg, const float* rays_o, const float* rays_d, int64_t n_rays, int H, int W,
+                            float focal, int ndc, float near, float far, int use_viewdirs, float* rays, int ray_ld,
+                            const float* t_rand, uint64_t seed, uint64_t offset, const uint64_t* offset_base, float* z_coarse,
+                            float* loss, snr_stream_t stream);
 /* parameter gradients of the training forward above (same cfg / networks / rays / ws): grad_coarse and grad_fine (flat
  * fp32) overwritten if accumulate == 0, else += ; fine == NULL: both passes accumulate into grad_coarse.
  * passes: SNR_PASS_FINE | SNR_PASS_COARSE — a data-parallel caller runs the fine pass, starts that network's all-reduce

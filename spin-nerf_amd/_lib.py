@@ -40,7 +40,7 @@ class Net(_c.Structure):            # snr_net
 
 class RenderConfig(_c.Structure):   # snr_render_config
     _fields_ = [("n_samples", _i), ("n_importance", _i), ("lindisp", _i), ("white_bkgd", _i), ("perturb", _i),
-                ("raw_noise_std", _f)]
+                ("raw_noise_std", _f), ("flags", _i)]
 
 
 class RenderWsLayout(_c.Structure):  # snr_render_ws_layout
@@ -99,6 +99,7 @@ SIGNATURES = {
     "snr_step_state_advance": (_i, [_p, _c.c_double, _c.c_double, _f, _f, _c.c_uint64, _p]),
     "snr_render_rays_fused_forward": (_i, [_RCFG, _NET, _NET, _p, _i, _l, _p, _p, _p, _p, _c.c_uint64, _c.c_uint64, _p, _p, _l,
                                            _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "snr_render_step_prepare": (_i, [_RCFG, _p, _p, _l, _i, _i, _f, _i, _f, _f, _i, _p, _i, _p, _c.c_uint64, _c.c_uint64, _p, _p, _p, _p]),
     "snr_render_rays_fused_backward": (_i, [_RCFG, _NET, _NET, _p, _i, _l, _p, _p, _p, _i, _i, _p]),
     "snr_make_rays": (_i, [_i, _i, _f, _c.POINTER(_f), _i, _i, _i, _i, _i, _f, _f, _i, _p, _i, _p]),
     "snr_sample_pdf": (_i, [_p, _p, _p, _l, _i, _i, _p, _p]),

@@ -21,7 +21,9 @@
 namespace snr {
 
 constexpr int kMaxPanels = 96;
-constexpr int kPanelLd = 320;   // LDS row length in floats (>= the widest weight matrix: 256 + 63)
+constexpr int kPanelCols = 320;  // columns kept per panel row (>= the widest weight matrix: 256 + 63)
+constexpr int kPanelLd = 321;    // LDS row length in floats: odd, so that the 32 rows a forward fragment's lanes read (same
+                                 // column, stride one row) fall into 32 different banks (a stride of 320 put them all into one)
 
 struct AdamPackNet {
   float* p;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a) {
   // store (the buffers may alias as far as the compiler knows: left in one loop, every iteration waits for its own loads)
   {
     const int lane_ = tid & 63, wave_ = tid >> 6;
-    constexpr int NJ = kPanelLd / 64;
+    constexpr int NJ = kPanelCols / 64;
     // every load of the panel first (8 rows x 5 column steps x 4 buffers in flight per lane: this short kernel is pure
     // latency), then the arithmetic and the stores
     float pv[8][NJ], gv[8][NJ], mv[8][NJ], vv[8][NJ];
@@ -231,7 +233,7 @@ static int launch_adam_pack(const snr_adam_pack_item* items, int n, float lr, fl
   for (int ei = 0; ei < a.T.n_entries; ++ei) {
     const PackEntry& E = a.T.e[ei];
     if (E.transposed) continue;
-    if (E.src[0].ld > kPanelLd || (E.src[1].ks > 0 && E.src[1].w_off != E.src[0].w_off)) return SNR_ERR_UNSUPPORTED;
+    if (E.src[0].ld > kPanelCols || (E.src[1].ks > 0 && E.src[1].w_off != E.src[0].w_off)) return SNR_ERR_UNSUPPORTED;
     for (int t = 0; t < E.n_tiles; ++t) {
       if (32 * t >= E.rows_valid) break;   // (a tile without valid rows holds no parameters)
       if (np >= kMaxPanels) return SNR_ERR_UNSUPPORTED;

@@ -116,7 +116,8 @@ extern "C" int snr_render_rays_fused_forward(const snr_render_config* cfg, const
   const int last0 = Nf == 0;   // the coarse pass is the final one
 
   // ---- coarse pass (run_nerf.py:646-692) ----
-  if (cfg->perturb && !t_rand) st = snr::sample_coarse_rng_impl(rays, ray_ld, n_rays, Nc, cfg->lindisp, seed, offset + 1, offset_base, F(L.z_coarse), stream);
+  if (cfg->flags & SNR_RENDER_Z_COARSE_READY) st = SNR_OK;   // snr_render_step_prepare wrote the stratified z_vals
+  else if (cfg->perturb && !t_rand) st = snr::sample_coarse_rng_impl(rays, ray_ld, n_rays, Nc, cfg->lindisp, seed, offset + 1, offset_base, F(L.z_coarse), stream);
   else st = snr_sample_coarse(rays, ray_ld, n_rays, Nc, cfg->lindisp, cfg->perturb ? t_rand : nullptr, F(L.z_coarse), stream);
   if (st != SNR_OK) return st;
   st = net_forward(coarse, rays, ray_ld, F(L.z_coarse), n_rays, Nc, F(L.raw0), train ? w + L.act0 : nullptr, stream);
@@ -125,7 +126,17 @@ extern "C" int snr_render_rays_fused_forward(const snr_render_config* cfg, const
   float* m_disp = last0 ? disp_map : disp0;
   float* m_acc = last0 ? acc_map : acc0;
   float* m_depth = last0 ? depth_map : F(L.depth0);
-  if (train) {
+  bool sampled = false;   // the hierarchical sampling ran inside the compositing launch
+  if (train && !last0) {
+    // compositing + loss + its backward of the coarse samples AND hierarchical sampling + sort from the weights, one kernel
+    st = snr::composite_train_sample_impl(F(L.raw0), C0, F(L.z_coarse), rays, ray_ld, noise0, cfg->raw_noise_std, seed, offset + 2,
+                                          offset_base, n_rays, Nc, cfg->white_bkgd, 0, target, n_rays_global, m_rgb, m_disp, m_acc,
+                                          m_depth, F(L.weights0), F(L.d_raw0), loss, cfg->perturb ? u : nullptr,
+                                          cfg->perturb && !u, offset + 3, Nf, F(L.z_vals), F(L.z_samples), z_std, stream);
+    sampled = st == SNR_OK;
+  }
+  if (sampled) {
+  } else if (train) {
     st = snr::composite_train_impl(F(L.raw0), C0, F(L.z_coarse), rays, ray_ld, noise0, cfg->raw_noise_std, seed, offset + 2,
                                    offset_base, n_rays, Nc, cfg->white_bkgd, 0, target, n_rays_global, m_rgb, m_disp, m_acc, m_depth, F(L.weights0),
                              F(L.d_raw0), loss, last0 ? loss + 1 : nullptr, stream);
@@ -137,7 +148,8 @@ extern "C" int snr_render_rays_fused_forward(const snr_render_config* cfg, const
   if (st != SNR_OK || last0) return st;
 
   // ---- hierarchical sampling + fine pass (run_nerf.py:694-713) ----
-  if (cfg->perturb && !u) st = snr::sample_fine_rng_impl(F(L.z_coarse), F(L.weights0), n_rays, Nc, Nf, seed, offset + 3, offset_base, F(L.z_vals), F(L.z_samples), z_std, stream);
+  if (sampled) st = SNR_OK;
+  else if (cfg->perturb && !u) st = snr::sample_fine_rng_impl(F(L.z_coarse), F(L.weights0), n_rays, Nc, Nf, seed, offset + 3, offset_base, F(L.z_vals), F(L.z_samples), z_std, stream);
   else st = snr_sample_fine(F(L.z_coarse), F(L.weights0), cfg->perturb ? u : nullptr, n_rays, Nc, Nf, F(L.z_vals), F(L.z_samples), z_std, stream);
   if (st != SNR_OK) return st;
   st = net_forward(f, rays, ray_ld, F(L.z_vals), n_rays, S, F(L.raw), train ? w + L.act : nullptr, stream);
@@ -186,4 +198,15 @@ extern "C" int snr_render_rays_fused_backward(const snr_render_config* cfg, cons
   if (!do_coarse) return SNR_OK;
   return net_backward(coarse, rays, ray_ld, F(L.z_coarse), n_rays, Nc, F(L.d_raw0), w + L.act0, ws0, grad_coarse, acc_c,
                       stream);
+}
+
+extern "C" int snr_render_step_prepare(const snr_render_config* cfg, const float* rays_o, const float* rays_d, int64_t n_rays, int H,
+                                       int W, float focal, int ndc, float near, float far, int use_viewdirs, float* rays, int ray_ld,
+                                       const float* t_rand, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
+                                       float* z_coarse, float* loss, snr_stream_t stream) {
+  if (!cfg) return SNR_ERR_NULL;
+  if (cfg->n_samples < 2) return SNR_ERR_SHAPE;
+  return snr::pack_rays_sample_impl(rays_o, rays_d, n_rays, H, W, focal, ndc, near, far, use_viewdirs, rays, ray_ld, cfg->n_samples,
+                                    cfg->lindisp, cfg->perturb ? t_rand : nullptr, cfg->perturb && !t_rand, seed, offset + 1,
+                                    offset_base, z_coarse, loss, loss ? 2 : 0, stream);
 }

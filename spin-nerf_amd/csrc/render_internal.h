@@ -16,4 +16,14 @@ int composite_train_impl(const float* raw, int C, const float* z, const float* r
                          int white, int detach, const float* target, int64_t n_rays_global, float* rgb_map, float* disp_map,
                          float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss, float* loss_also,
                          snr_stream_t stream);
+int composite_train_sample_impl(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
+                                float noise_std, uint64_t seed, uint64_t offset, const uint64_t* base, int64_t n_rays, int Nc,
+                                int white, int detach, const float* target, int64_t n_rays_global, float* rgb_map, float* disp_map,
+                                float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss, const float* u,
+                                int use_rng_u, uint64_t offset_u, int Nf, float* z_out, float* z_samples, float* z_std,
+                                snr_stream_t stream);
+int pack_rays_sample_impl(const float* rays_o, const float* rays_d, int64_t n_rays, int H, int W, float focal, int ndc, float near,
+                          float far, int use_viewdirs, float* rays, int ld, int N, int lindisp, const float* t_rand, int use_rng,
+                          uint64_t seed, uint64_t offset, const uint64_t* base, float* z_vals, float* zero, int n_zero,
+                          snr_stream_t stream);
 }  // namespace snr

@@ -353,18 +353,16 @@ __global__ __launch_bounds__(256) void composite_train_kernel(
 // times (forward, the backward's accumulate pass, the backward's reverse pass with its prefix recomputation), each chunk
 // waiting for its own loads — with one wave per SIMD that latency chain was the kernel (16.5 us for 1024 rays x 192
 // samples).  Arithmetic and its order are those of composite_fwd_ray / composite_bwd_ray with g_disp = g_acc = g_depth = 0.
+// one ray by one wave; returns the ray's squared colour error.  w_keep (LDS, may be null): the weights once more, for a
+// hierarchical-sampling stage fused behind this one (composite_train_sample_kernel)
 template <int NCH>
-__global__ __launch_bounds__(256) void composite_train_reg_kernel(
+__device__ __forceinline__ float composite_train_ray(
     const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
-    NoiseSrc ns, int64_t n_rays, int S, int white, int detach, const float* __restrict__ target, float inv_count,
+    const NoiseSrc& ns, int64_t ray, int S, int white, int detach, const float* __restrict__ target, float inv_count,
     float* __restrict__ rgb_map, float* __restrict__ disp_map, float* __restrict__ acc_map,
-    float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, float* __restrict__ loss,
-    float* __restrict__ loss_also) {
-  __shared__ float sq[kRaysPerBlock];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, int lane, float* w_keep) {
   float e2 = 0.f;
-  if (ray < n_rays) {
+  {
     const float* rd = rays + ray * ld + 3;
     const float* zr = z_vals + ray * S;
     float z[NCH], zn[NCH], r0[NCH], r1[NCH], r2[NCH], s[NCH];
@@ -410,7 +408,7 @@ __global__ __launch_bounds__(256) void composite_train_reg_kernel(
       Ti[c] = T * excl;
       w[c] = a * Ti[c];
       T = T * __shfl(incl, kWave - 1, kWave);
-      if (in[c]) weights[ray * S + i] = w[c];
+      if (in[c]) { weights[ray * S + i] = w[c]; if (w_keep) w_keep[i] = w[c]; }
       sr += w[c] * c0[c]; sg += w[c] * c1[c]; sb += w[c] * c2[c]; sd += w[c] * z[c]; sa += w[c];
     }
     sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
@@ -452,6 +450,23 @@ __global__ __launch_bounds__(256) void composite_train_reg_kernel(
       }
     }
   }
+  return e2;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void composite_train_reg_kernel(
+    const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
+    NoiseSrc ns, int64_t n_rays, int S, int white, int detach, const float* __restrict__ target, float inv_count,
+    float* __restrict__ rgb_map, float* __restrict__ disp_map, float* __restrict__ acc_map,
+    float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, float* __restrict__ loss,
+    float* __restrict__ loss_also) {
+  __shared__ float sq[kRaysPerBlock];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+  float e2 = 0.f;
+  if (ray < n_rays)
+    e2 = composite_train_ray<NCH>(raw, C, z_vals, rays, ld, ns, ray, S, white, detach, target, inv_count, rgb_map, disp_map, acc_map,
+                                  depth_map, weights, d_raw, lane, nullptr);
   if (lane == 0) sq[wv] = e2;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -466,25 +481,16 @@ __global__ __launch_bounds__(256) void composite_train_reg_kernel(
 // hierarchical sampling (helpers:304-347) + sort of the union (run_nerf.py:702) + z_std (:726)
 // one wave per ray; LDS per wave: cdf[Nc-1], bins[Nc-1], sort buffer[pow2 >= Nc+Nf]
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ z_coarse,
-                                                          const float* __restrict__ weights,
-                                                          const float* __restrict__ u_in, int64_t n_rays, int Nc, int Nf,
-                                                          int npow2, float* __restrict__ z_out,
-                                                          float* __restrict__ z_samples, float* __restrict__ z_std,
-                                                          int direct, int use_rng, Rng rng) {
-  extern __shared__ float lds[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+// one ray by one wave.  zc: the ray's coarse z (direct: its nb bin positions); wr: the ray's weights such that wr[i + 1] is
+// the weight of bin i (global memory, or the LDS copy a fused compositing stage left); cdf: 2 * nb + npow2 floats of LDS
+__device__ __forceinline__ void sample_fine_ray(const float* __restrict__ zc, const float* wr,
+                                                const float* __restrict__ u_in, int64_t ray, int Nc, int Nf, int npow2,
+                                                float* __restrict__ z_out, float* __restrict__ z_samples,
+                                                float* __restrict__ z_std, int direct, int use_rng, const Rng& rng,
+                                                float* cdf, int lane) {
   const int nb = Nc - 1;   // number of bins (midpoints), cdf has nb entries, pdf nb-1
-  const int per_wave = 2 * nb + npow2;
-  float* cdf = lds + wv * per_wave;
   float* bins = cdf + nb;
   float* srt = bins + nb;
-  if (ray >= n_rays) return;  // whole wave exits together; barriers below are wave-local
-  // direct (snr_sample_pdf): z_coarse holds the nb bin positions themselves and weights the nb-1 bin weights;
-  // no union / sort.  Otherwise bins are the midpoints of z_coarse and the pdf comes from weights[1:-1].
-  const float* zc = z_coarse + ray * (direct ? nb : Nc);
-  const float* wr = direct ? weights + ray * (nb - 1) - 1 : weights + ray * Nc;
 
   // pdf = (w[1:-1] + 1e-5) / sum   (helpers:306-307; the slice is run_nerf.py:699)
   float tot = 0.f;
@@ -556,6 +562,60 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
   for (int i = lane; i < Nc + Nf; i += kWave) z_out[ray * (Nc + Nf) + i] = srt[i];
 }
 
+__global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ z_coarse,
+                                                          const float* __restrict__ weights,
+                                                          const float* __restrict__ u_in, int64_t n_rays, int Nc, int Nf,
+                                                          int npow2, float* __restrict__ z_out,
+                                                          float* __restrict__ z_samples, float* __restrict__ z_std,
+                                                          int direct, int use_rng, Rng rng) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+  const int nb = Nc - 1;
+  const int per_wave = 2 * nb + npow2;
+  if (ray >= n_rays) return;  // whole wave exits together; barriers inside are wave-local
+  // direct (snr_sample_pdf): z_coarse holds the nb bin positions themselves and weights the nb-1 bin weights;
+  // no union / sort.  Otherwise bins are the midpoints of z_coarse and the pdf comes from weights[1:-1].
+  const float* zc = z_coarse + ray * (direct ? nb : Nc);
+  const float* wr = direct ? weights + ray * (nb - 1) - 1 : weights + ray * Nc;
+  sample_fine_ray(zc, wr, u_in, ray, Nc, Nf, npow2, z_out, z_samples, z_std, direct, use_rng, rng, lds + wv * per_wave, lane);
+}
+
+// The coarse pass's tail and the fine pass's head of a TRAINING render_rays as one kernel (run_nerf.py:680-702 + the loss
+// term and autograd's first step): compositing forward + loss + compositing backward of the coarse samples, then
+// hierarchical sampling + sort from the weights just computed — they never leave the CU (LDS) between the two stages, and
+// one launch (with its ramp: a wave per ray, 1024 rays) replaces two.  Nc <= 64.
+__global__ __launch_bounds__(256) void composite_train_sample_kernel(
+    const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
+    NoiseSrc ns, int64_t n_rays, int Nc, int white, int detach, const float* __restrict__ target, float inv_count,
+    float* __restrict__ rgb_map, float* __restrict__ disp_map, float* __restrict__ acc_map,
+    float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, float* __restrict__ loss,
+    const float* __restrict__ u_in, int Nf, int npow2, float* __restrict__ z_out, float* __restrict__ z_samples,
+    float* __restrict__ z_std, int use_rng, Rng rng) {
+  extern __shared__ float lds[];
+  __shared__ float sq[kRaysPerBlock];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+  const int nb = Nc - 1;
+  const int per_wave = Nc + 2 * nb + npow2;
+  float* w_keep = lds + wv * per_wave;
+  float e2 = 0.f;
+  if (ray < n_rays) {
+    e2 = composite_train_ray<1>(raw, C, z_vals, rays, ld, ns, ray, Nc, white, detach, target, inv_count, rgb_map, disp_map, acc_map,
+                                depth_map, weights, d_raw, lane, w_keep);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    sample_fine_ray(z_vals + ray * Nc, w_keep, u_in, ray, Nc, Nf, npow2, z_out, z_samples, z_std, 0, use_rng, rng, w_keep + Nc, lane);
+  }
+  if (lane == 0) sq[wv] = e2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < kRaysPerBlock; ++k) t += sq[k];
+    atomicAdd(loss, t * inv_count);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // rays (helpers:249-260, 283-300; run_nerf.py:117-153)
 // ------------------------------------------------------------------------------------------
@@ -620,6 +680,34 @@ __global__ void pack_rays_kernel(const float* __restrict__ rays_o, const float* 
   const float v[3] = {vs[0], vs[1], vs[2]};
   write_ray_row(o, d, v, H, W, focal, ndc, ndc_near, near_rows ? near_rows[idx] : near, far_rows ? far_rows[idx] : far,
                 depths ? depths + idx : nullptr, use_viewdirs, rays + idx * ld);
+}
+
+// The head of a training render() as ONE kernel: the packed row of every ray (pack_rays_kernel's plain case), the stratified
+// z_vals of its coarse samples (sample_coarse_kernel: run_nerf.py:646-668) and the zero fill of the step's loss accumulator —
+// three launches of a few microseconds each before.  One thread per (ray, sample); the thread of sample 0 packs the row.
+__global__ void pack_rays_sample_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, int64_t n, int H,
+                                        int W, float focal, int ndc, float ndc_near, float near, float far, int use_viewdirs,
+                                        float* __restrict__ rays, int ld, int N, int lindisp,
+                                        const float* __restrict__ t_rand, int use_rng, Rng rng, float* __restrict__ z_vals,
+                                        float* __restrict__ zero, int n_zero) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n_zero) zero[idx] = 0.f;
+  if (idx >= n * N) return;
+  const int64_t r = idx / N;
+  const int i = (int)(idx - r * N);
+  if (i == 0) {
+    float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+    float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const float v[3] = {d[0], d[1], d[2]};
+    write_ray_row(o, d, v, H, W, focal, ndc, ndc_near, near, far, nullptr, use_viewdirs, rays + r * ld);
+  }
+  const float z = z_at(near, far, i, N, lindisp);
+  if (!t_rand && !use_rng) { z_vals[idx] = z; return; }
+  const float zl = i > 0 ? z_at(near, far, i - 1, N, lindisp) : z;
+  const float zu = i < N - 1 ? z_at(near, far, i + 1, N, lindisp) : z;
+  const float lower = i > 0 ? .5f * (z + zl) : z;       // run_nerf.py:656-658
+  const float upper = i < N - 1 ? .5f * (zu + z) : z;
+  z_vals[idx] = lower + (upper - lower) * (t_rand ? t_rand[idx] : rng_uniform(rng, idx));  // run_nerf.py:668
 }
 
 // positional encoding as a standalone op (Embedder.embed, helpers:22-52): out[i] = [x, sin(2^0 x), cos(2^0 x), ...,
@@ -963,6 +1051,48 @@ int snr::composite_train_impl(const float* raw, int C, const float* z, const flo
   }
   return launch_status();
 }
+// composite_train of the coarse samples + hierarchical sampling from its weights, one kernel (Nc <= 64, 16-byte aligned raw rows)
+int snr::composite_train_sample_impl(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
+                                     float noise_std, uint64_t seed, uint64_t offset, const uint64_t* base, int64_t n_rays, int Nc,
+                                     int white, int detach, const float* target, int64_t n_rays_global, float* rgb_map,
+                                     float* disp_map, float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss,
+                                     const float* u, int use_rng_u, uint64_t offset_u, int Nf, float* z_out, float* z_samples,
+                                     float* z_std, snr_stream_t stream) {
+  SNR_CHECK_ARG(raw && z && rays && target && rgb_map && disp_map && acc_map && depth_map && weights && d_raw && loss && z_out,
+                SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_rays > 0 && n_rays_global >= n_rays && Nc >= 3 && Nc <= kWave && Nf >= 1 && C >= 4 && ld >= 6, SNR_ERR_SHAPE);
+  if (C == 4 && ((((uintptr_t)raw) | ((uintptr_t)d_raw)) & 15) != 0) return SNR_ERR_UNSUPPORTED;
+  int npow2 = 2;
+  while (npow2 < Nc + Nf) npow2 <<= 1;
+  const size_t lds = (size_t)kRaysPerBlock * (Nc + 2 * (Nc - 1) + npow2) * sizeof(float);
+  if (lds > 48 * 1024) return SNR_ERR_UNSUPPORTED;
+  const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  const NoiseSrc ns{noise, (!noise && noise_std > 0.f) ? 1 : 0, make_rng(seed, offset, base), noise_std};
+  {
+    ProfScope ps(K_COMPOSITE_FWD, (hipStream_t)stream);
+    composite_train_sample_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(
+        raw, C, z, rays, ld, ns, n_rays, Nc, white, detach, target, 1.f / (3.f * (float)n_rays_global), rgb_map, disp_map, acc_map,
+        depth_map, weights, d_raw, loss, u, Nf, npow2, z_out, z_samples, z_std, use_rng_u, make_rng(seed, offset_u, base));
+  }
+  return launch_status();
+}
+
+int snr::pack_rays_sample_impl(const float* rays_o, const float* rays_d, int64_t n_rays, int H, int W, float focal, int ndc,
+                               float near, float far, int use_viewdirs, float* rays, int ld, int N, int lindisp,
+                               const float* t_rand, int use_rng, uint64_t seed, uint64_t offset, const uint64_t* base, float* z_vals,
+                               float* zero, int n_zero, snr_stream_t stream) {
+  SNR_CHECK_ARG(rays_o && rays_d && rays && z_vals, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_rays > 0 && H > 0 && W > 0 && N > 0 && ld >= 8 + (use_viewdirs ? 3 : 0) && n_zero >= 0 && n_zero <= 256, SNR_ERR_SHAPE);
+  const int64_t n = n_rays * N;
+  {
+    ProfScope ps(K_MAKE_RAYS, (hipStream_t)stream);
+    pack_rays_sample_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        rays_o, rays_d, n_rays, H, W, focal, ndc, 1.f, near, far, use_viewdirs, rays, ld, N, lindisp, t_rand, use_rng,
+        make_rng(seed, offset, base), z_vals, zero, n_zero);
+  }
+  return launch_status();
+}
+
 extern "C" int snr_composite_train(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
                                    float noise_std, uint64_t seed, uint64_t offset, int64_t n_rays, int S, int white,
                                    int detach, const float* target, int64_t n_rays_global, float* rgb_map,

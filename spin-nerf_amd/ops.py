@@ -482,18 +482,25 @@ def _net_struct(net):
 
 
 def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bkgd, perturb, raw_noise_std, seed, offset,
-                  target, loss, n_rays_global=None, randoms=None, offset_base=None):
+                  target, loss, n_rays_global=None, randoms=None, offset_base=None, prepare=None):
     """render_rays + the loss terms + the compositing backward of one training step in one library call.  ``net_f`` None
     with N_importance > 0 = the coarse network evaluated twice.  Consumes the Philox offsets offset+1 .. offset+4.
     Returns a FusedRender; fused_backward(handle) gives the parameter gradients.  ``target`` None (and ``loss`` None) =
     inference: forward only, nothing saved for a backward.  ``offset_base`` = device tensor holding a snr_step_state (its
-    first field is added to the draw offsets at run time: graph replays)."""
+    first field is added to the draw offsets at run time: graph replays).
+    ``prepare`` = dict(rays_o, rays_d, H, W, focal, ndc, near, far, use_viewdirs) instead of packed ``rays``: the packed rows,
+    the stratified z_vals and the zero fill of ``loss`` are made by ONE launch (snr_render_step_prepare) in front of the
+    forward; the rows are in the returned handle (``.rays``)."""
     import ctypes
     lib = _lib.load()
     rnd = randoms or {}
+    if prepare is not None:
+        ro, rd = f32c(prepare["rays_o"]), f32c(prepare["rays_d"])
+        n = ro.shape[0]
+        rays = torch.empty(n, 11 if prepare["use_viewdirs"] else 8, device=ro.device, dtype=torch.float32)
     n = rays.shape[0]
     rc = _lib.RenderConfig(int(N_samples), int(N_importance), int(bool(lindisp)), int(bool(white_bkgd)),
-                           int(perturb > 0.), float(raw_noise_std))
+                           int(perturb > 0.), float(raw_noise_std), 1 if prepare is not None else 0)
     sc, pc = _net_struct(net_c)
     two = N_importance > 0 and net_f is not None and net_f is not net_c
     sf, pf = _net_struct(net_f) if two else (None, None)
@@ -508,6 +515,13 @@ def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bk
     flat = maps8.view(8, -1)
     disp, acc, depth, disp0, acc0, z_std = (flat[2 + k, :n] for k in range(6))   # the first n floats of a slab each
     arr = {k: (f32c(rnd[k]) if rnd.get(k) is not None else None) for k in ("t_rand", "u", "noise_c", "noise_f")}
+    if prepare is not None:
+        z_coarse = ws[L.z_coarse:]
+        check(lib.snr_render_step_prepare(ctypes.byref(rc), ptr(ro), ptr(rd), n, int(prepare["H"]), int(prepare["W"]),
+                                          float(prepare["focal"]), int(bool(prepare["ndc"])), float(prepare["near"]),
+                                          float(prepare["far"]), int(bool(prepare["use_viewdirs"])), ptr(rays), rays.shape[1],
+                                          ptr(arr["t_rand"]), int(seed), int(offset), ptr(offset_base), ptr(z_coarse), ptr(loss),
+                                          stream()), "snr_render_step_prepare")
     check(lib.snr_render_rays_fused_forward(
         ctypes.byref(rc), ctypes.byref(sc), fptr, ptr(rays), rays.shape[1], n, ptr(arr["t_rand"]), ptr(arr["u"]),
         ptr(arr["noise_c"]), ptr(arr["noise_f"]), int(seed), int(offset), ptr(offset_base), ptr(target),

@@ -152,18 +152,18 @@ class RenderTrainer:
         white, lindisp = kw.get('white_bkgd', False), kw.get('lindisp', False)
         net_c = kw['network_fn']
         net_f = (kw.get('network_fine') or net_c) if Nf > 0 else None
-        rays = ops.pack_rays(batch_rays[0], batch_rays[1], H, W, focal, ndc=kw.get('ndc', True), near=float(kw.get('near', 0.)),
-                             far=float(kw.get('far', 1.)), use_viewdirs=kw.get('use_viewdirs', False))
-        vd = rays[:, -3:] if rays.shape[1] > 9 else None
         target = ops.f32c(target_s)
-        loss = torch.zeros(2, device=rays.device)      # [0] = the step's loss, [1] = the final render's term alone
         seed = self._seed
 
         if os.environ.get("SNR_NO_FUSED_STEP") != "1":
-            # the whole launch sequence as two library calls (snr_render_rays_fused_forward / _backward)
+            # the whole launch sequence as library calls: snr_render_step_prepare (ray rows + stratified z + the zero fill of the
+            # loss: one launch), snr_render_rays_fused_forward / _backward
             two = Nf > 0 and net_f is not net_c
-            h = ops.fused_forward(net_c, net_f if two else None, rays, Nc, Nf, lindisp, white, perturb, std, seed, self._draws,
-                                  target, loss, randoms=rnd)   # local mean: Adam folds 1 / world_size in
+            loss = torch.empty(2, device=batch_rays.device)      # [0] = the step's loss, [1] = the final render's term alone
+            prep = dict(rays_o=batch_rays[0], rays_d=batch_rays[1], H=H, W=W, focal=focal, ndc=kw.get('ndc', True),
+                        near=float(kw.get('near', 0.)), far=float(kw.get('far', 1.)), use_viewdirs=kw.get('use_viewdirs', False))
+            h = ops.fused_forward(net_c, net_f if two else None, None, Nc, Nf, lindisp, white, perturb, std, seed, self._draws,
+                                  target, loss, randoms=rnd, prepare=prep)   # local mean: Adam folds 1 / world_size in
             self._draws += 4
             if two:
                 # both backward passes as ONE launch sequence (snr_mlp_backward_multi: one chain launch, one weight-gradient
@@ -185,6 +185,11 @@ class RenderTrainer:
                 net_c.flat.grad = g_c
             self.apply_gradients()
             return loss[0], h.rgb
+
+        rays = ops.pack_rays(batch_rays[0], batch_rays[1], H, W, focal, ndc=kw.get('ndc', True), near=float(kw.get('near', 0.)),
+                             far=float(kw.get('far', 1.)), use_viewdirs=kw.get('use_viewdirs', False))
+        vd = rays[:, -3:] if rays.shape[1] > 9 else None
+        loss = torch.zeros(2, device=rays.device)      # [0] = the step's loss, [1] = the final render's term alone
 
         def draw():
             self._draws += 1
@@ -557,7 +562,7 @@ class RenderTrainer:
         lr = self._lr
         from .nerf import NeRF
         live = [(n, m, v) for n, m, v in zip(self.nets, self.m, self.v) if n.flat.grad is not None]   # torch.optim.Adam skips parameters without a gradient
-        fused = [t for t in live if type(t[0]) is NeRF and os.environ.get("SNR_NO_ADAM_PACK") != "1"]
+        fused = [t for t in live if type(t[0]) is NeRF and t[0].flat.is_cuda and os.environ.get("SNR_NO_ADAM_PACK") != "1"]
         if fused:
             # Adam + the re-pack of the weights of both MLPs: ONE launch (csrc/adam_pack.hip) instead of two Adam and two pack launches
             for k in range(0, len(fused), 2):

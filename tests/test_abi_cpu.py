@@ -222,3 +222,44 @@ def test_fused_render_rays_layout_and_argument_checks_on_host(S):
     assert ctypes.sizeof(S._lib.StepState) == 40
     assert lib.snr_render_rays_fused_backward(ctypes.byref(rc), ctypes.byref(net), None, blob, 11, n, blob, blob, None, 0, 0,
                                               None) == -2       # no pass selected
+
+
+def test_process_wide_settings_are_read_once_and_thread_safe(S, monkeypatch):
+    """VERDICT r03 item 7.  The library's only process-wide state besides the profiling log: the SNR_* environment switches
+    and each device's CU count, read ONCE (include/spinnerf_hip.h, conventions) — no launch counter, no per-call getenv.
+    (a) eight host threads asking for the backward workspace size at once (the first call initialises the settings) all get
+    the same answer; (b) changing the environment afterwards changes nothing until snr_tunables_reload(); (c) the new entry
+    points validate their arguments on the host."""
+    import ctypes
+    import threading
+    lib = S._lib.load()
+    cfg = S._lib.MlpConfig(10, 4, 0, 1, 4, S._lib.PREC_BF16)
+    n = 1024 * 192
+    monkeypatch.delenv("SNR_PAIR_SLOTS", raising=False)
+    lib.snr_tunables_reload()
+    out = [None] * 8
+
+    def ask(i):
+        out[i] = [lib.snr_mlp_bwd_ws_bytes(cfg, n) for _ in range(200)]
+    ts = [threading.Thread(target=ask, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    base = out[0][0]
+    assert base > 0 and all(v == base for o in out for v in o)
+    monkeypatch.setenv("SNR_PAIR_SLOTS", "64")          # half the pair slots: a smaller partial-sum buffer ...
+    assert lib.snr_mlp_bwd_ws_bytes(cfg, n) == base      # ... but not before the switches are read again
+    lib.snr_tunables_reload()
+    assert 0 < lib.snr_mlp_bwd_ws_bytes(cfg, n) < base
+    monkeypatch.delenv("SNR_PAIR_SLOTS")
+    lib.snr_tunables_reload()
+    assert lib.snr_mlp_bwd_ws_bytes(cfg, n) == base
+    # new entry points: argument checks before any device access
+    assert lib.snr_mlp_backward_multi(None, 1, None) == -1
+    items = (S._lib.MlpBwdItem * 1)()
+    assert lib.snr_mlp_backward_multi(items, 3, None) == -2 and lib.snr_mlp_backward_multi(items, 1, None) == -1
+    assert lib.snr_adam_pack_multi(None, 1, 5e-4, 0.9, 0.999, 1e-8, 1, 1.0, None, None) == -1
+    ap = (S._lib.AdamPackItem * 1)()
+    assert lib.snr_adam_pack_multi(ap, 1, 5e-4, 0.9, 0.999, 1e-8, 0, 1.0, None, None) == -2   # step is 1-based
+    rc = S._lib.RenderConfig(64, 128, 0, 0, 1, 1.0, 0)
+    assert lib.snr_render_step_prepare(ctypes.byref(rc), None, None, 8, 4, 4, 1.0, 0, 0.0, 1.0, 1, None, 11, None, 0, 0, None,
+                                       None, None, None) == -1

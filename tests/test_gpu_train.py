@@ -79,7 +79,7 @@ def train(precision, iters, n_rand=1024, seed=0, white=False, noise=1.0, n_fine=
     return psnrs, view_psnr(2 * math.pi * 0.5 / 6)
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1500)
 def test_bf16_training_matches_fp32_psnr():
     """Black background + raw_noise_std=1 (the reference's config value).  The noise is a regulariser, not a
     necessity: noise-free runs reach 28 dB on the training views in both precisions (tests/probes/mlp_noise_free.py) but
@@ -89,12 +89,14 @@ def test_bf16_training_matches_fp32_psnr():
 
     The comparison is PAIRED by seed (same initial weights, ray batches and in-kernel draws for both precisions) and made
     on the mean of the last 400 of 1200 steps.  Measured on MI355X over 12 seeds (round 3): paired difference bf16 - fp32
-    -0.00 dB, standard deviation of a pair 0.17 dB (largest 0.34); round 2's 4000-iteration, 12-seed run
-    (profiles/r02_psnr_gap.txt): +0.09 +- 0.12 dB.  Held-out views on a wider field of view, 64 + 128 samples:
-    profiles/r03_psnr_heldout.txt (+0.12 +- 0.24 dB over the pairs that end in the same basin).  Gates: the mean of four
-    pairs within 0.3 dB (3.5 standard errors), every pair within 0.8 dB, both paths above 24 dB — BASELINE.json asks for
-    +-0.1 dB on the statue scene, which is not in the container."""
-    iters, seeds = 1200, (0, 1, 2, 3)
+    -0.00 dB, standard deviation of a pair 0.17 dB (largest 0.34).  The pre-registered experiment of round 4 (a scene in
+    which every ray ends on a surface, 16 training + 4 held-out cameras, 64 + 128 samples, 2500 steps; statistic, seeds and
+    "no exclusions" fixed before the run: tests/probes/psnr_r04.py, profiles/r04_psnr_heldout.txt) gave, over ALL pairs,
+    held-out +0.11 +- 0.12 dB (16 pairs) and last-500-step training PSNR +0.009 +- 0.032 dB, no basin flip in either
+    precision.  Gates here: the mean of EIGHT pairs within 0.15 dB (2.5 standard errors at the measured
+    0.17 dB per pair), every pair within 0.8 dB, both paths above 24 dB — BASELINE.json asks for +-0.1 dB on the statue scene,
+    which is not in the container: that claim stays untested."""
+    iters, seeds = 1200, (0, 1, 2, 3, 4, 5, 6, 7)
     diffs = []
     for seed in seeds:
         p32, t32 = train("fp32", iters, seed=seed)
@@ -110,4 +112,4 @@ def test_bf16_training_matches_fp32_psnr():
         assert abs(tail16 - tail32) < 0.8, (seed, tail16, tail32)
         diffs.append(tail16 - tail32)
     print(f"paired differences bf16 - fp32: {[round(d, 3) for d in diffs]}, mean {np.mean(diffs):+.3f} dB")
-    assert abs(float(np.mean(diffs))) < 0.3, diffs
+    assert abs(float(np.mean(diffs))) < 0.15, diffs
