@@ -60,8 +60,10 @@ template <int P> __device__ __forceinline__ int slot_of(int kind, int f, int g, 
   return (P == kBF16) ? 8 * g + e : 2 * e + g;   // SRC_OUT: raw channel
 }
 
+constexpr int kApThreads = 1024, kApWaves = kApThreads / 64;   // 16 waves per panel: this kernel is latency (a few dependent
+                                                                // load -> LDS -> store rounds); it needs waves, not work per wave
 template <int P>
-__global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a) {
+__global__ __launch_bounds__(kApThreads) void adam_pack_kernel(AdamPackArgs a) {
   using Frag = typename Mma<P>::Frag;
   constexpr int EPF = Prec<P>::EPF, FPT = Prec<P>::FPT;
   __shared__ float W[32 * kPanelLd];
@@ -77,19 +79,36 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a) {
   if (pi == a.n_panels) {
     // ---- the bias block: every bias parameter once; padding entries of the block stay zero ----
     float* bias = (float*)(N.blob + (int64_t)total_frags * 1024);
-    for (int idx = tid; idx < T.bias_floats; idx += 256) {
-      for (int b = 0; b < T.n_bias; ++b) {
-        const int r = idx - T.b[b].dst;
-        if (r >= 0 && r < T.b[b].count && r < T.b[b].n_valid) {
-          const int gi = T.b[b].src + r;
-          float m = N.m[gi], v = N.v[gi];
-          const float pn = adam_one(N.p[gi], N.g[gi], m, v, c);
-          N.p[gi] = pn; N.m[gi] = m; N.v[gi] = v;
-          bias[idx] = pn;
+    // (as in the panels: every load first, then the arithmetic and the stores — one dependent load -> store round per
+    //  batch of biases would serialise this workgroup)
+    constexpr int NB = 3;    // >= bias_floats / kApThreads (2496 floats with view directions)
+    int gi[NB];
+    float pv[NB], gv[NB], mv[NB], vv[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int idx = tid + kApThreads * k;
+      gi[k] = -1;
+      if (idx < T.bias_floats) {
+        for (int b = 0; b < T.n_bias; ++b) {
+          const int r = idx - T.b[b].dst;
+          if (r >= 0 && r < T.b[b].count && r < T.b[b].n_valid) gi[k] = T.b[b].src + r;
         }
       }
     }
-    for (int idx = tid; idx < a.orphan_count; idx += 256) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const bool ok = gi[k] >= 0;
+      pv[k] = ok ? N.p[gi[k]] : 0.f; gv[k] = ok ? N.g[gi[k]] : 0.f; mv[k] = ok ? N.m[gi[k]] : 0.f; vv[k] = ok ? N.v[gi[k]] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      if (gi[k] >= 0) {
+        const float pn = adam_one(pv[k], gv[k], mv[k], vv[k], c);
+        N.p[gi[k]] = pn; N.m[gi[k]] = mv[k]; N.v[gi[k]] = vv[k];
+        bias[tid + kApThreads * k] = pn;
+      }
+    }
+    for (int idx = tid; idx < a.orphan_count; idx += kApThreads) {
       const int gi = a.orphan_begin + idx;
       float m = N.m[gi], v = N.v[gi];
       const float pn = adam_one(N.p[gi], N.g[gi], m, v, c);
@@ -106,17 +125,18 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a) {
   nrows = nrows > 32 ? 32 : nrows;
 
   // ---- 1. Adam on the panel, new parameters to LDS (rows beyond the valid ones: zero) ----
-  // wave w takes rows 8 w .. 8 w + 7, its lanes run along a row (coalesced); all loads of a row are issued before the first
+  // wave w takes rows 2 w, 2 w + 1, its lanes run along a row (coalesced); all loads of a row are issued before the first
   // store (the buffers may alias as far as the compiler knows: left in one loop, every iteration waits for its own loads)
   {
     const int lane_ = tid & 63, wave_ = tid >> 6;
     constexpr int NJ = kPanelCols / 64;
-    // every load of the panel first (8 rows x 5 column steps x 4 buffers in flight per lane: this short kernel is pure
-    // latency), then the arithmetic and the stores
-    float pv[8][NJ], gv[8][NJ], mv[8][NJ], vv[8][NJ];
+    // every load of this wave's rows first (2 rows x 5 column steps x 4 buffers in flight per lane), then the arithmetic and
+    // the stores
+    constexpr int RW = 32 / kApWaves;   // rows per wave
+    float pv[RW][NJ], gv[RW][NJ], mv[RW][NJ], vv[RW][NJ];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = 8 * wave_ + rr;
+    for (int rr = 0; rr < RW; ++rr) {
+      const int r = RW * wave_ + rr;
       const int64_t g0 = (int64_t)w_off + (int64_t)(n0 + r) * ld;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -129,8 +149,8 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a) {
       }
     }
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = 8 * wave_ + rr;
+    for (int rr = 0; rr < RW; ++rr) {
+      const int r = RW * wave_ + rr;
       const int64_t g0 = (int64_t)w_off + (int64_t)(n0 + r) * ld;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a) {
 
   // ---- 2. the forward fragments of this row tile ----
   const int per_tile = E.src[0].ks + E.src[1].ks;
-  for (int fl = wave; fl < per_tile; fl += 4) {
+  for (int fl = wave; fl < per_tile; fl += kApWaves) {
     const int s = fl >= E.src[0].ks ? 1 : 0;
     const int f = s ? fl - E.src[0].ks : fl;
     const PackSrc& S = E.src[s];
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a) {
       const int nq = q1 - q0;
       if (nq <= 0) continue;
       const int items = ET.n_tiles * nq;
-      for (int it = wave; it < items; it += 4) {
+      for (int it = wave; it < items; it += kApWaves) {
         const int kt = it / nq, q = q0 + it % nq;
         const int row = 32 * kt + i;   // input neuron (weight column S.col_off + row)
         Frag out = Mma<P>::zero();
@@ -241,6 +261,7 @@ static int launch_adam_pack(const snr_adam_pack_item* items, int n, float lr, fl
     }
   }
   a.n_panels = np; a.n_nets = n;
+  if (a.T.bias_floats > 3 * kApThreads) return SNR_ERR_UNSUPPORTED;
   if (!c->use_viewdirs) {
     const ParamLayout L = make_param_layout(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
     a.orphan_begin = (int)L.w_views;
@@ -252,7 +273,7 @@ static int launch_adam_pack(const snr_adam_pack_item* items, int n, float lr, fl
   a.bc2_sqrt = (float)sqrt(1.0 - powi_host((double)b2, step));
   {
     ProfScope ps(K_ADAM, s);
-    adam_pack_kernel<P><<<dim3((unsigned)(n * (np + 1))), dim3(256), 0, s>>>(a);
+    adam_pack_kernel<P><<<dim3((unsigned)(n * (np + 1))), dim3(kApThreads), 0, s>>>(a);
   }
   return launch_status();
 }
