@@ -92,8 +92,8 @@ def test_bf16_training_matches_fp32_psnr():
     -0.00 dB, standard deviation of a pair 0.17 dB (largest 0.34).  The pre-registered experiment of round 4 (a scene in
     which every ray ends on a surface, 16 training + 4 held-out cameras, 64 + 128 samples, 2500 steps; statistic, seeds and
     "no exclusions" fixed before the run: tests/probes/psnr_r04.py, profiles/r04_psnr_heldout.txt) gave, over ALL pairs,
-    held-out +0.11 +- 0.12 dB (16 pairs) and last-500-step training PSNR +0.009 +- 0.032 dB, no basin flip in either
-    precision.  Gates here: the mean of EIGHT pairs within 0.15 dB (2.5 standard errors at the measured
+    held-out -0.053 +- 0.069 dB (32 pairs; the planned 16: +0.107 +- 0.116) and last-500-step training PSNR -0.024 +- 0.026 dB,
+    no basin flip in either precision.  Gates here: the mean of EIGHT pairs within 0.15 dB (2.5 standard errors at the measured
     0.17 dB per pair), every pair within 0.8 dB, both paths above 24 dB — BASELINE.json asks for +-0.1 dB on the statue scene,
     which is not in the container: that claim stays untested."""
     iters, seeds = 1200, (0, 1, 2, 3, 4, 5, 6, 7)
