@@ -260,6 +260,11 @@ template <int P, int WAVES_> struct Pipe {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] = b0;
       }
+#ifndef SNR_TWO_CHAIN
+#define SNR_TWO_CHAIN 0   // A/B builds (round 4): 1 = the dgrad chains (no bias, bf16) accumulate even and odd k-steps of an output
+#endif                    // tile in two independent accumulators (tests/probes/mfma_feed.hip: 82 % vs 75 % of the MFMA rate)
+      constexpr bool TWO = SNR_TWO_CHAIN && !BIAS && P == kBF16 && K >= 4 && NJ == 1;
+      f32x16 acc2;   // (TWO) the odd k-steps' chain; its first MFMA takes the constant 0 as C
       static_for<0, K>([&](auto F_) {
         constexpr int f = decltype(F_)::value;
         constexpr int i = nt * K + f;
@@ -273,10 +278,16 @@ template <int P, int WAVES_> struct Pipe {
           return 4 * n;
         }();
         lds_wait<ahead + nb>(w[i % G]);
+        if constexpr (TWO && (f & 1)) {
+          const f32x16 z16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          const Frag& src = f < KA ? sa[f] : sb[f - KA];
+          acc2 = M::mma(w[i % G], src, f == 1 ? z16 : acc2);
+        } else {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if constexpr (f < KA) acc[j] = M::mma(w[i % G], sa[j * SA + f], acc[j]);
-          else acc[j] = M::mma(w[i % G], sb[j * SB + (f - KA)], acc[j]);
+          for (int j = 0; j < NJ; ++j) {
+            if constexpr (f < KA) acc[j] = M::mma(w[i % G], sa[j * SA + f], acc[j]);
+            else acc[j] = M::mma(w[i % G], sb[j * SB + (f - KA)], acc[j]);
+          }
         }
         if constexpr (f == 0) {
 #if !(SNR_ABLATE & 4)   // timing experiment: no activation stores
@@ -291,6 +302,7 @@ template <int P, int WAVES_> struct Pipe {
         if constexpr (i + G < NF) load(std::integral_constant<int, i + G>{});
         if (NJ > 1 || (f & 1)) issue_one();   // one DMA piece per ~64 cycles of MFMA
       });
+      if constexpr (TWO) acc[0] = acc[0] + acc2;
       if constexpr (OVERLAP) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) prev[j] = acc[j];
