@@ -74,6 +74,28 @@ def _worker(rank, world, port, out):
     gathered = [torch.zeros_like(net.flat.data) for _ in range(world)]
     dist.all_gather(gathered, net.flat.data)
     assert all(torch.equal(gathered[0], x) for x in gathered)
+
+    # round 4: the direct step writes BOTH networks' gradients into the two halves of one buffer and exchanges them with a
+    # single all-reduce whose work object stands for both networks (train.py: _step_direct); apply_gradients must wait for it
+    # once per network, start no collective of its own, and leave identical replicas
+    torch.manual_seed(7)                   # same init on every rank
+    nets = [S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True) for _ in range(2)]
+    tr2 = train.RenderTrainer({"network_fn": nets[0], "network_fine": nets[1]}, lrate=1e-2, world_size=world)
+    n0 = nets[0].flat.numel()
+    g_both = torch.cat([torch.full((n0,), float(rank + 1)), torch.full((nets[1].flat.numel(),), float(10 * (rank + 1)))])
+    nets[0].flat.grad, nets[1].flat.grad = g_both[:n0], g_both[n0:]
+    work = dist.all_reduce(g_both, op=dist.ReduceOp.SUM, async_op=True)
+    tr2._works[0] = tr2._works[1] = work
+    started = []
+    tr2._start_all_reduce = lambda i, p: started.append(i)
+    tr2.apply_gradients()
+    assert not started and not tr2._works
+    tot = float(sum(range(1, world + 1)))
+    assert torch.equal(nets[0].flat.grad, torch.full((n0,), tot)) and torch.equal(nets[1].flat.grad, torch.full_like(nets[1].flat.grad, 10 * tot))
+    for n in nets:
+        gathered = [torch.zeros_like(n.flat.data) for _ in range(world)]
+        dist.all_gather(gathered, n.flat.data)
+        assert all(torch.equal(gathered[0], x) for x in gathered)
     dist.destroy_process_group()
 
 
