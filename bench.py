@@ -500,7 +500,7 @@ def main():
         "step_route": "captured HIP graph replay (SNR_STEP_GRAPH=1)" if graph_route else
                       "library calls per step: step_prepare, render_rays_fused_forward, render_rays_fused_backward (both networks' "
                       "backward as one launch sequence), adam_pack_multi",
-        "launches_per_step": sum(v["launches_per_step"] for v in kernels.values()) + (1 if "mlp_wgrad_reduce" in kernels else 0),
+        "launches_per_step": sum(v["launches_per_step"] for v in kernels.values()),   # every key of `kernels` is one kernel (prof.cpp)
     }
     if dist_info is not None:
         out["distributed"] = dist_info

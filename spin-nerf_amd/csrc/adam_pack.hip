@@ -272,7 +272,7 @@ static int launch_adam_pack(const snr_adam_pack_item* items, int n, float lr, fl
   a.bc1 = (float)(1.0 - powi_host((double)b1, step));
   a.bc2_sqrt = (float)sqrt(1.0 - powi_host((double)b2, step));
   {
-    ProfScope ps(K_ADAM, s);
+    ProfScope ps(K_ADAM_PACK, s);
     adam_pack_kernel<P><<<dim3((unsigned)(n * (np + 1))), dim3(kApThreads), 0, s>>>(a);
   }
   return launch_status();

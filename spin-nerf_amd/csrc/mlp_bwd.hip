@@ -350,11 +350,12 @@ static int backward_plain(const BwdItem& it, hipStream_t s) {
     ReduceArgs ra{};
     if (!append_reduce(ra, w, 0, it.grad_params, it.accumulate)) return SNR_ERR_UNSUPPORTED;
     mlp_wgrad_reduce_kernel<P><<<dim3((kReducePerOut + 255) / 256, (unsigned)ra.n_outs), dim3(256), 0, s>>>(ra);
-    if (c->use_viewdirs) {
-      PostArgs pa{};
-      pa.net[0] = post_net(it, w.post);
-      wgrad_post_kernel<P><<<dim3(kPostTiles), dim3(256), 0, s>>>(pa);
-    }
+  }
+  if (c->use_viewdirs) {
+    ProfScope ps(K_WGRAD_POST, s);
+    PostArgs pa{};
+    pa.net[0] = post_net(it, w.post);
+    wgrad_post_kernel<P><<<dim3(kPostTiles), dim3(256), 0, s>>>(pa);
   }
   return launch_status();
 }
@@ -407,7 +408,10 @@ static int backward_merged(const BwdItem* items, int n, hipStream_t s) {
   {
     ProfScope ps(K_MLP_WGRAD_REDUCE, s);
     mlp_wgrad_reduce_kernel<P><<<dim3((kReducePerOut + 255) / 256, (unsigned)ra.n_outs), dim3(256), 0, s>>>(ra);
-    if (vd) wgrad_post_kernel<P><<<dim3((unsigned)(kPostTiles * n)), dim3(256), 0, s>>>(post);
+  }
+  if (vd) {
+    ProfScope ps(K_WGRAD_POST, s);
+    wgrad_post_kernel<P><<<dim3((unsigned)(kPostTiles * n)), dim3(256), 0, s>>>(post);
   }
   return launch_status();
 }

@@ -16,7 +16,8 @@ hipEvent_t g_open_a = nullptr;
 int g_open_id = -1;
 const char* kNames[K_COUNT] = {"mlp_pack", "mlp_fwd", "mlp_dgrad", "mlp_wgrad", "mlp_wgrad_reduce", "sample_coarse",
                                "composite_fwd", "composite_bwd", "sample_fine", "make_rays", "adam", "hg_pack", "hg_fwd",
-                               "hg_bwd", "mlp_wgrad_pair"};
+                               "hg_bwd", "mlp_wgrad_pair", "composite_train", "composite_train_reg", "composite_train_sample",
+                               "pack_rays_sample", "pack_rays", "adam_pack", "wgrad_post"};
 hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;

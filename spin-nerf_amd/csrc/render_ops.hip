@@ -1035,13 +1035,13 @@ int snr::composite_train_impl(const float* raw, int C, const float* z, const flo
   const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   const NoiseSrc ns{noise, (!noise && noise_std > 0.f) ? 1 : 0, make_rng(seed, offset, base), noise_std};
   {
-    ProfScope ps(K_COMPOSITE_FWD, (hipStream_t)stream);
-    const float inv_count = 1.f / (3.f * (float)n_rays_global);
     const int nch = (S + kWave - 1) / kWave;
-#define SNR_CT_ARGS raw, C, z, rays, ld, ns, n_rays, S, white, detach, target, inv_count, rgb_map, disp_map, acc_map, depth_map, \
-                    weights, d_raw, loss, loss_also
     // 16-byte raw rows (C == 4) need 16-byte aligned bases for the vector accesses of the register-resident version
     const bool aligned = C != 4 || ((((uintptr_t)raw) | ((uintptr_t)d_raw)) & 15) == 0;
+    ProfScope ps(nch <= 4 && aligned ? K_COMPOSITE_TRAIN_REG : K_COMPOSITE_TRAIN, (hipStream_t)stream);
+    const float inv_count = 1.f / (3.f * (float)n_rays_global);
+#define SNR_CT_ARGS raw, C, z, rays, ld, ns, n_rays, S, white, detach, target, inv_count, rgb_map, disp_map, acc_map, depth_map, \
+                    weights, d_raw, loss, loss_also
     if (nch == 1 && aligned) composite_train_reg_kernel<1><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(SNR_CT_ARGS);
     else if (nch == 2 && aligned) composite_train_reg_kernel<2><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(SNR_CT_ARGS);
     else if (nch == 3 && aligned) composite_train_reg_kernel<3><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(SNR_CT_ARGS);
@@ -1069,7 +1069,7 @@ int snr::composite_train_sample_impl(const float* raw, int C, const float* z, co
   const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   const NoiseSrc ns{noise, (!noise && noise_std > 0.f) ? 1 : 0, make_rng(seed, offset, base), noise_std};
   {
-    ProfScope ps(K_COMPOSITE_FWD, (hipStream_t)stream);
+    ProfScope ps(K_COMPOSITE_TRAIN_SAMPLE, (hipStream_t)stream);
     composite_train_sample_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(
         raw, C, z, rays, ld, ns, n_rays, Nc, white, detach, target, 1.f / (3.f * (float)n_rays_global), rgb_map, disp_map, acc_map,
         depth_map, weights, d_raw, loss, u, Nf, npow2, z_out, z_samples, z_std, use_rng_u, make_rng(seed, offset_u, base));
@@ -1085,7 +1085,7 @@ int snr::pack_rays_sample_impl(const float* rays_o, const float* rays_d, int64_t
   SNR_CHECK_ARG(n_rays > 0 && H > 0 && W > 0 && N > 0 && ld >= 8 + (use_viewdirs ? 3 : 0) && n_zero >= 0 && n_zero <= 256, SNR_ERR_SHAPE);
   const int64_t n = n_rays * N;
   {
-    ProfScope ps(K_MAKE_RAYS, (hipStream_t)stream);
+    ProfScope ps(K_PACK_RAYS_SAMPLE, (hipStream_t)stream);
     pack_rays_sample_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
         rays_o, rays_d, n_rays, H, W, focal, ndc, 1.f, near, far, use_viewdirs, rays, ld, N, lindisp, t_rand, use_rng,
         make_rng(seed, offset, base), z_vals, zero, n_zero);
@@ -1125,7 +1125,7 @@ extern "C" int snr_pack_rays(const float* rays_o, const float* rays_d, const flo
   SNR_CHECK_ARG(rays_o && rays_d && rays, SNR_ERR_NULL);
   SNR_CHECK_ARG(n_rays > 0 && H > 0 && W > 0 && ld >= 8 + (depths ? 1 : 0) + (use_viewdirs ? 3 : 0), SNR_ERR_SHAPE);
   {
-    ProfScope ps(K_MAKE_RAYS, (hipStream_t)stream);
+    ProfScope ps(K_PACK_RAYS, (hipStream_t)stream);
     pack_rays_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
         rays_o, rays_d, view_src, n_rays, H, W, focal, ndc, ndc_near, near, far, near_rows, far_rows, depths,
         use_viewdirs, rays, ld);

@@ -23,8 +23,8 @@ for name, a in (("inference", None), ("train", act)):
         lib.snr_mlp_forward(net.cfg, L.ptr(packed), L.ptr(pts), None, 0, None, L.ptr(vd), 3, M, 192, L.ptr(raw), L.ptr(a), L.stream())
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print(f"{os.environ.get('SNR_LIB','base'):>50s} {name:9s} {dt*1e3:.3f} ms  {M*1186816/dt/1e12:.0f} TF")
-    if hasattr(lib, "snr_debug_read"):
+    if hasattr(lib, "snr_debug_read_fwd"):
         buf = (ctypes.c_ulonglong * 8)()
-        lib.snr_debug_read(buf)
+        lib.snr_debug_read_fwd(buf)
         tw, tb, ti, na, tk, nw = [buf[i] for i in range(6)]
         print(f"    per wave: kernel {tk/nw:.0f} cyc, acquires {na/nw:.0f}, wait {tw/nw:.0f} ({tw/na:.0f}/acq), barrier {tb/nw:.0f} ({tb/na:.0f}/acq), issue {ti/nw:.0f} ({ti/na:.0f}/acq)  [s_memtime ticks]")
