@@ -25,6 +25,7 @@
 #include "mlp_device.h"
 #include "mlp_wgrad.h"
 #include "mlp_wgrad_pair.h"
+#include "mlp_chain2.h"
 
 namespace snr {
 
@@ -48,7 +49,10 @@ struct DgradArgs {
 // for its whole life (its weight stream is that network's)
 struct DgradMulti { int n; DgradArgs net[kMaxReduceNets]; };
 
-template <int P, bool VD>
+// SAVE_EVEN = false (bf16 with selective recompute): d z0, d z2, d z4, d z6 are not written, and d z0 is not even computed —
+// nothing in this kernel consumes it, and the weight-gradient pass rebuilds it from d z1 (round 5: the last 256 x 256 stage of
+// the chain, a ninth of its MFMAs and of its weight stream, used to be computed and dropped).
+template <int P, bool VD, bool SAVE_EVEN>
 __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_kernel(DgradMulti mm) {
   const DgradArgs& a = mm.net[(mm.n > 1 && (int)blockIdx.x >= mm.net[1].block0) ? 1 : 0];
   using B = Blob<P>;
@@ -83,14 +87,22 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
     // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section for every sample tile of this wave
     // (uniform base) + (lane offset) addressing, section bases derived at the point of use: mlp_fwd.hip
     const uint32_t lane_even = g * 16 + sj * 32, lane_odd = g * 16 + act_row<P>(sj, 1) * 32;
-    auto ws_store = [&](int k_sec, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
+    auto ws_store_par = [&](auto PAR_, int k_sec, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
       constexpr int n = decltype(N_)::value, stride = decltype(STRIDE_)::value, NT = decltype(NT_)::value;
 #pragma unroll
       for (int jt = 0; jt < NJ; ++jt) {
         int64_t tl = WL.n_tiles;
         asm volatile("" : "+s"(tl));
-        store_tile_slice<P, n, NT>(a.ws + (tl * k_sec + (tile0 + jt) * n) * 1024, src + jt * stride, nt, lane_even, lane_odd);
+        store_tile_slice<P, n, NT, decltype(PAR_)::value>(a.ws + (tl * k_sec + (tile0 + jt) * n) * 1024, src + jt * stride, nt, lane_even, lane_odd);
       }
+    };
+    // a saved d z section's even fragments leave from the stage that produces them, the odd ones from the next stage (mlp_device.h)
+    constexpr bool kSplit = SNR_STORE_SPLIT && P == kBF16;
+    using PALL = std::integral_constant<int, -1>;
+    using PEVEN = std::integral_constant<int, 0>;
+    using PODD = std::integral_constant<int, kSplit ? 1 : -1>;
+    auto ws_store = [&](int k_sec, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
+      ws_store_par(PALL{}, k_sec, N_, src, STRIDE_, nt, NT_);
     };
     // ReLU flags of a stage, 16 B per lane.  Also asm (a load the compiler sees is waited for with vmcnt(0) at
     // its first use if anything else is pending).  Completion: loads retire in order, so once at most W
@@ -139,8 +151,9 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
     };
 
     // generic stage: dst = mask * (W^T [sa|sb]); NT output tiles
+    // k_out >= 0: the stage's output is a saved section of NOUT fragments per tile
     auto stage = [&](auto KA_, auto KB_, auto NT_, auto SA_, auto SB_, const Frag* sa, const Frag* sb, Frag* dst,
-                     bool use_mask, auto&& pre) {
+                     bool use_mask, auto&& pre, int k_out, auto NOUT_) {
       constexpr int KA = decltype(KA_)::value, KB = decltype(KB_)::value, NT = decltype(NT_)::value;
       constexpr int SA = decltype(SA_)::value, SB = decltype(SB_)::value;
       pipe.template run_tiles<KA, KB, NT, NJ, SA, SB>(
@@ -149,6 +162,9 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
             Frag* out = dst + jt * KS_H + nt * FPT;
             if constexpr (P == kBF16) {   // flag layout: mlp_device.h
               finish_dgrad_bf16(acc, out, use_mask, mk_cur[jt][nt >> 1], 8 * (nt & 1));
+              if constexpr (kSplit) {
+                if (k_out >= 0 && jt == NJ - 1) ws_store_par(PEVEN{}, k_out, NOUT_, dst, IH{}, nt, NT_);
+              }
             } else {
               if (use_mask) {
                 const unsigned bits = mk_cur[jt][nt >> 1] >> (16 * (nt & 1));
@@ -167,22 +183,22 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
       masks_ready(W1{}, mk_cur);   // used right away: everything but the one younger load has to be back
       // d z9 = relu'(h9) * (W_rgb^T d rgb)                 -> hB[.][0..KS_H9)
       stage(I1{}, I0{}, I4{}, I1{}, I1{}, &dout[0], &dout[0], &hB[0][0], true,
-            [&](int nt) { ws_store(WL.k_dout(), I1{}, &dout[0], I1{}, nt, I4{}); });
+            [&](int nt) { ws_store(WL.k_dout(), I1{}, &dout[0], I1{}, nt, I4{}); }, WL.k_dz9(), IH9{});
       // d feat = W_views[:, :256]^T d z9                    -> hA
       stage(IH9{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], false,
-            [&](int nt) { ws_store(WL.k_dz9(), IH9{}, &hB[0][0], IH{}, nt, I8{}); });
+            [&](int nt) { ws_store_par(PODD{}, WL.k_dz9(), IH9{}, &hB[0][0], IH{}, nt, I8{}); }, -1, IH{});
       // d z7 = relu'(h7) * (W_feat^T d feat + W_alpha^T d alpha) -> hB
       roll_masks(W6{});
       mask_load(AL.k_mask(6), mk_next);
       stage(IH{}, I1{}, I8{}, IH{}, I1{}, &hA[0][0], &dout[0], &hB[0][0], true,
-            [&](int) {});   // d feat stays in registers: its weight gradient follows from d z9 (mlp_wgrad.h)
+            [&](int) {}, WL.k_dz(7), IH{});   // d feat stays in registers: its weight gradient follows from d z9 (mlp_wgrad.h)
     } else {
       mask_load(AL.k_mask(7), mk_cur);
       mask_load(AL.k_mask(6), mk_next);
       masks_ready(W1{}, mk_cur);
       // d z7 = relu'(h7) * (W_out^T d raw)                  -> hB
       stage(I1{}, I0{}, I8{}, I1{}, I1{}, &dout[0], &dout[0], &hB[0][0], true,
-            [&](int nt) { ws_store(WL.k_dout(), I1{}, &dout[0], I1{}, nt, I8{}); });
+            [&](int nt) { ws_store(WL.k_dout(), I1{}, &dout[0], I1{}, nt, I8{}); }, WL.k_dz(7), IH{});
       masks_ready(W1{}, mk_next);   // only one block (2 DMA pieces) was issued behind this load so far
     }
     // d z_{i-1} = relu'(h_{i-1}) * (W_i^T d z_i), i = 7..1 ; d z7 is in hB
@@ -192,19 +208,174 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
       roll_masks(W6{});
       mask_load(AL.k_mask(i - 2), mk_next);
       stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], true,
-            [&](int nt) { ws_store(WL.k_dz(i), IH{}, &hB[0][0], IH{}, nt, I8{}); });
+            [&](int nt) { ws_store_par(PODD{}, WL.k_dz(i), IH{}, &hB[0][0], IH{}, nt, I8{}); }, SAVE_EVEN ? WL.k_dz(i - 1) : -1, IH{});
       roll_masks(W6{});
-      mask_load(AL.k_mask(i - 3 >= 0 ? i - 3 : 0), mk_next);
+      if constexpr (SAVE_EVEN) mask_load(AL.k_mask(i - 3 >= 0 ? i - 3 : 0), mk_next);
+      else if (i - 3 > 0) mask_load(AL.k_mask(i - 3), mk_next);   // (mask 0 belongs to the d z0 stage: no load is left in flight)
       stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], true,
-            [&](int nt) { if (a.save_even) ws_store(WL.k_dz(i - 1), IH{}, &hA[0][0], IH{}, nt, I8{}); });
+            [&](int nt) { if constexpr (SAVE_EVEN) ws_store_par(PODD{}, WL.k_dz(i - 1), IH{}, &hA[0][0], IH{}, nt, I8{}); }, WL.k_dz(i - 2), IH{});
     }
-    // i = 1: d z0 from d z1 (hB) -> hA
-    roll_masks(W6{});
-    stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], true,
-          [&](int nt) { ws_store(WL.k_dz(1), IH{}, &hB[0][0], IH{}, nt, I8{}); });
-    if (a.save_even) ws_store(WL.k_dz(0), IH{}, &hA[0][0], IH{}, 0, I1{});
+    if constexpr (SAVE_EVEN) {
+      // i = 1: d z0 from d z1 (hB) -> hA
+      roll_masks(W6{});
+      stage(IH{}, I0{}, I8{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], true,
+            [&](int nt) { ws_store_par(PODD{}, WL.k_dz(1), IH{}, &hB[0][0], IH{}, nt, I8{}); }, WL.k_dz(0), IH{});
+      ws_store_par(PODD{}, WL.k_dz(0), IH{}, &hA[0][0], IH{}, 0, I1{});
+    } else {
+      ws_store_par(PODD{}, WL.k_dz(1), IH{}, &hB[0][0], IH{}, 0, I1{});   // the chain ends at d z1 (the stream wraps 4 blocks early)
+    }
   }
   pipe.drain();
+}
+
+
+// ------------------------------------------------------------------------------------------
+// 1b. chain2 dgrad (bf16, view directions, selective recompute): 8 compute waves + 2 loaders + 2 storers, mlp_chain2.h
+// ------------------------------------------------------------------------------------------
+// chunk list of a pass, in staging order: d out (1 fragment, last spill slot), the 4 tiles of d z9, the 8 tiles each of
+// d z7, d z5, d z3, d z1.  A tile t is staged in slot t (t < NREG: a register-resident tile, the slot is rewritten by tile
+// t + NREG) or in its own spill slot t - NREG.  Sections: 0 d out, 1 d z9, 2 + j d z(7 - 2 j).
+struct Dgrad2Table {
+  static constexpr int kChunks = c2::BwdMap::kChunks;
+  static constexpr c2::Chunk chunk(int c) {
+    if (c == 0) return c2::Chunk{0, 0, 1, c2::kSpillTiles - 1};
+    const int q = c < 5 ? c - 1 : (c - 5) % 8;
+    return c2::Chunk{c < 5 ? 1 : 2 + (c - 5) / 8, 2 * q, 2, q < c2::kNReg ? q : q - c2::kNReg};
+  }
+};
+
+__global__ __launch_bounds__((64 * c2::kWaves)) void mlp_dgrad2_kernel(DgradMulti mm) {
+  using namespace c2;
+  const DgradArgs& a = mm.net[(mm.n > 1 && (int)blockIdx.x >= mm.net[1].block0) ? 1 : 0];
+  using B = Blob<kBF16>;
+  constexpr int P = kBF16, KS_H = B::KS_H, KS_H9 = B::KS_H9, NREG = kNReg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem + kBiasBytes;
+  char* spill0 = smem + kBiasBytes + kRing2Bytes;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  LdsFlags fl = (LdsFlags)SNR_LDS(smem + kFlagsOffset);
+  if (tid < (int)(sizeof(Flags) / 4)) ((LdsWord)fl)[tid] = 0u;
+  if ((int)blockIdx.x == a.block0 && a.zero_words && tid < a.n_zero) a.zero_words[tid] = 0u;
+  __syncthreads();
+
+  const ActLayout<P> AL(a.n_samples, true);
+  const WsLayout<P> WL(a.n_samples, true);
+  const int64_t n_wg = AL.n_tiles / kCompute;
+  const int first = (int)blockIdx.x - a.block0;
+  const int n_pass = first < n_wg ? (int)((n_wg - first + a.blocks - 1) / a.blocks) : 0;
+
+  if (wave >= kCompute + 2) {          // storers
+    storer_run<Dgrad2Table>(spill0, fl, wave - kCompute - 2, lane, n_pass, [&](int sec, int pass, int w) {
+      const int64_t tile = ((int64_t)first + (int64_t)pass * a.blocks) * kCompute + w;
+      const int k = sec == 0 ? WL.k_dout() : (sec == 1 ? WL.k_dz9() : WL.k_dz(7 - 2 * (sec - 2)));
+      const int n = sec == 0 ? 1 : (sec == 1 ? KS_H9 : KS_H);
+      return a.ws + (WL.n_tiles * k + tile * n) * 1024;
+    });
+    return;
+  }
+  if (wave >= kCompute) {              // loaders
+    loader_run<2>(ring, fl, a.blob_bwd, BwdMap::kBlocks, BwdMap::kPassBlocks, n_pass, wave - kCompute, lane);
+    return;
+  }
+
+  const int sj = lane & 31, g = lane >> 5;
+  Cw<2> cw;
+  cw.ring_lane = ring + lane * 16;
+  cw.spill_lane = spill0 + wave * kSpillBytes + lane * 16;
+  cw.bias_lds = nullptr;
+  cw.fl = fl;
+  cw.my_done = &fl->done[wave];
+  cw.my_staged = &fl->staged[wave];
+  cw.my_stored = &fl->stored[wave];
+  cw.g = g;
+  cw.seen[0] = cw.seen[1] = 0;
+  cw.base = 0;
+  cw.n_staged = cw.seen_stored = 0;
+#pragma unroll
+  for (int i = 0; i < kSpillTiles; ++i) cw.slot_chunk[i] = 0;
+
+  for (int64_t wg = first; wg < n_wg; wg += a.blocks) {
+    const int64_t tile0 = wg * kCompute + wave;
+    // d raw -> OUT fragment: k-slot 8 g + e = channel (mlp_dgrad_kernel)
+    Frag dout = Mma<P>::zero();
+    {
+      const int64_t m = tile0 * 32 + sj;
+      if (m < a.n_samples) {
+        const float* dr = a.d_raw + m * a.out_ch;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ch = 8 * g + e;
+          if (ch < a.out_ch) Mma<P>::set(dout, e, dr[ch]);
+        }
+      }
+    }
+    auto mask_of = [&](int k_sec) { return *((const u32x4*)(a.act + (AL.n_tiles * k_sec + tile0) * 1024) + lane); };
+    u32x4 mk = mask_of(AL.k_mask9()), mk_next = mask_of(AL.k_mask(7));
+
+    Frag in[KS_H], outr[2 * NREG];
+    // epilogue of an output tile: relu' mask, two fragments; SAVED: the tile is a chunk for the storers
+    auto tile_out = [&](auto SAVED_, auto MASK_, auto LAST_, auto NT_, const f32x16& acc) {
+      constexpr int nt = decltype(NT_)::value;
+      constexpr bool SAVED = decltype(SAVED_)::value, LAST = decltype(LAST_)::value;
+      Frag o[2];
+      finish_dgrad_bf16(acc, o, decltype(MASK_)::value, mk[nt >> 1], 8 * (nt & 1));
+      constexpr int slot = nt < NREG ? nt : nt - NREG;
+      if constexpr (nt < NREG) { outr[2 * nt] = o[0]; outr[2 * nt + 1] = o[1]; }
+      if constexpr (LAST) { in[2 * nt] = o[0]; in[2 * nt + 1] = o[1]; }   // the stage's input is dead: no reload of the last tile
+      if constexpr (SAVED || (nt >= NREG && !LAST)) {
+        cw.slot_free<slot>();
+        cw.spill_write<slot, 0>(o[0]); cw.spill_write<slot, 1>(o[1]);
+        if constexpr (SAVED) cw.post_chunk<slot>();
+      }
+    };
+    auto next_in = [&](auto NT_) {
+      constexpr int NT = decltype(NT_)::value;
+      static_for<0, 2 * NT>([&](auto F_) {
+        constexpr int f = decltype(F_)::value;
+        if constexpr (f < 2 * NREG) in[f] = outr[f];
+        else if constexpr (f >= 2 * NT - 2) {}   // the last tile went straight to in[]
+        else in[f] = cw.spill_read<(f - 2 * NREG) / 2, (f - 2 * NREG) % 2>();
+      });
+    };
+    using TT = std::true_type;
+    using FF = std::false_type;
+    using I8 = std::integral_constant<int, 8>;
+    using I4 = std::integral_constant<int, 4>;
+
+    // chunk 0: d out, one fragment in the last spill slot
+    cw.slot_free<kSpillTiles - 1>();
+    cw.spill_write<kSpillTiles - 1, 0>(dout);
+    cw.post_chunk<kSpillTiles - 1>();
+    // d z9 = relu'(h9) * (W_rgb^T d rgb): 4 tiles
+    cw.stage<BwdMap::B0, BwdMap::N0, 1, 0, 4, false>(&dout, &dout, 0, [&](auto NT_, f32x16& acc) {
+      tile_out(TT{}, TT{}, std::integral_constant<bool, decltype(NT_)::value == 3>{}, NT_, acc);
+    });
+    next_in(I4{});
+    mk = mk_next; mk_next = mask_of(AL.k_mask(6));
+    // d feat = W_views[:, :256]^T d z9: not saved (its weight gradient follows from d z9: mlp_wgrad.h), no relu in front of it
+    cw.stage<BwdMap::B1, BwdMap::N1, KS_H9, 0, 8, false>(in, in, 0, [&](auto NT_, f32x16& acc) {
+      tile_out(FF{}, FF{}, std::integral_constant<bool, decltype(NT_)::value == 7>{}, NT_, acc);
+    });
+    next_in(I8{});
+    // d z7 = relu'(h7) * (W_feat^T d feat + W_alpha^T d alpha)
+    cw.stage<BwdMap::B2, BwdMap::N2, KS_H, 1, 8, false>(in, &dout, 0, [&](auto NT_, f32x16& acc) {
+      tile_out(TT{}, TT{}, std::integral_constant<bool, decltype(NT_)::value == 7>{}, NT_, acc);
+    });
+    next_in(I8{});
+    // d z_{6-j} = relu'(h_{6-j}) * (W_{7-j}^T d z_{7-j}), j = 0..5; the odd ones are saved
+    static_for<0, 6>([&](auto J_) {
+      constexpr int j = decltype(J_)::value;
+      mk = mk_next;
+      if constexpr (j < 5) mk_next = mask_of(AL.k_mask(5 - j));
+      cw.stage<BwdMap::B3 + j * BwdMap::NH, BwdMap::NH, KS_H, 0, 8, false>(in, in, 0, [&](auto NT_, f32x16& acc) {
+        tile_out(std::integral_constant<bool, (j & 1) == 1>{}, TT{}, std::integral_constant<bool, decltype(NT_)::value == 7>{}, NT_, acc);
+      });
+      if constexpr (j < 5) next_in(I8{});
+    });
+    cw.base += BwdMap::kPassBlocks;
+  }
 }
 
 }  // namespace snr
@@ -269,7 +440,7 @@ template <int P> static DgradArgs dgrad_args(const BwdItem& it, bool save_even) 
   const PackTable T = make_pack_table<P>(c->multires, c->multires_views, c->use_viewdirs, c->out_ch, c->i_embed == -1);
   DgradArgs d{};
   d.blob_bwd = (const char*)it.packed + (int64_t)T.fwd_frags * 1024;
-  d.bwd_blocks = T.bwd_frags / kBlockFrags;
+  d.bwd_blocks = T.bwd_frags / kBlockFrags - (save_even ? 0 : 8 * Blob<P>::KS_H / kBlockFrags);   // without the d z0 stage
   d.d_raw = it.d_raw; d.n_samples = it.n_samples; d.out_ch = c->out_ch;
   d.act = (const char*)it.act; d.ws = (char*)it.ws;
   d.save_even = save_even;
@@ -277,12 +448,12 @@ template <int P> static DgradArgs dgrad_args(const BwdItem& it, bool save_even) 
 }
 
 // the chains of 1..2 networks in one launch; the workgroups are shared out in proportion to the networks' tiles
-template <int P, bool VD>
+template <int P, bool VD, bool SAVE_EVEN>
 static int launch_dgrad(DgradMulti& m, hipStream_t s) {
   constexpr int per_wg = ChainCfg<P, true>::WAVES * ChainCfg<P, true>::NJ;
   int64_t n_wg[kMaxReduceNets], total = 0;
   for (int i = 0; i < m.n; ++i) { n_wg[i] = padded_tiles<P>(m.net[i].n_samples) / per_wg; total += n_wg[i]; }
-  const int64_t budget = 1024;   // one workgroup per CU is resident; the rest grid-stride
+  const int64_t budget = tunables().chain_grid > 0 ? tunables().chain_grid : 1024;   // one workgroup per CU is resident; the rest grid-stride
   int block = 0;
   for (int i = 0; i < m.n; ++i) {
     int64_t g = total <= budget ? n_wg[i] : n_wg[i] * budget / total;
@@ -290,10 +461,30 @@ static int launch_dgrad(DgradMulti& m, hipStream_t s) {
     m.net[i].block0 = block; m.net[i].blocks = (int)g; block += (int)g;
   }
   const int lds = kRingBytes;
-  if (int e = ensure_dynamic_lds<&mlp_dgrad_kernel<P, VD>>(lds)) return e;
+  if (int e = ensure_dynamic_lds<&mlp_dgrad_kernel<P, VD, SAVE_EVEN>>(lds)) return e;
   {
     ProfScope ps(K_MLP_DGRAD, s);
-    mlp_dgrad_kernel<P, VD><<<dim3((unsigned)block), dim3(64 * ChainCfg<P, true>::WAVES), lds, s>>>(m);
+    mlp_dgrad_kernel<P, VD, SAVE_EVEN><<<dim3((unsigned)block), dim3(64 * ChainCfg<P, true>::WAVES), lds, s>>>(m);
+  }
+  return launch_status();
+}
+
+// chain2: persistent workgroups (one per CU), shared out in proportion to the networks' tiles
+static int launch_dgrad2(DgradMulti& m, hipStream_t s) {
+  int64_t n_wg[kMaxReduceNets], total = 0;
+  for (int i = 0; i < m.n; ++i) { n_wg[i] = padded_tiles<kBF16>(m.net[i].n_samples) / c2::kCompute; total += n_wg[i]; }
+  const int64_t budget = cu_count();
+  int block = 0;
+  for (int i = 0; i < m.n; ++i) {
+    int64_t g = total <= budget ? n_wg[i] : n_wg[i] * budget / total;
+    if (g < 1) g = 1;
+    m.net[i].block0 = block; m.net[i].blocks = (int)g; block += (int)g;
+  }
+  const int lds = c2::kBiasBytes + c2::kRing2Bytes + c2::kCompute * c2::kSpillBytes;
+  if (int e = ensure_dynamic_lds<&mlp_dgrad2_kernel>(lds)) return e;
+  {
+    ProfScope ps(K_MLP_DGRAD, s);
+    mlp_dgrad2_kernel<<<dim3((unsigned)block), dim3(64 * c2::kWaves), lds, s>>>(m);
   }
   return launch_status();
 }
@@ -329,7 +520,7 @@ static int backward_plain(const BwdItem& it, hipStream_t s) {
   DgradMulti m{};
   m.n = 1;
   m.net[0] = dgrad_args<P>(it, true);
-  st = c->use_viewdirs ? launch_dgrad<P, true>(m, s) : launch_dgrad<P, false>(m, s);
+  st = c->use_viewdirs ? launch_dgrad<P, true, true>(m, s) : launch_dgrad<P, false, true>(m, s);
   if (st != SNR_OK) return st;
   int64_t pf; int total_splits;
   WgradArgs w = make_jobs<P>(c, it.n_samples, &pf, &total_splits, false);
@@ -396,7 +587,8 @@ static int backward_merged(const BwdItem* items, int n, hipStream_t s) {
     if (!append_reduce(ra, nets[i].red, i, it.grad_params, it.accumulate)) return SNR_ERR_UNSUPPORTED;
     post.net[i] = post_net(it, g_block);
   }
-  st = vd ? launch_dgrad<P, true>(m, s) : launch_dgrad<P, false>(m, s);
+  if (vd && tunables().chain2) st = launch_dgrad2(m, s);
+  else st = vd ? launch_dgrad<P, true, false>(m, s) : launch_dgrad<P, false, false>(m, s);
   if (st != SNR_OK) return st;
   if (int e = ensure_dynamic_lds<&mlp_wgrad_pair_kernel>(kLdsBytes)) return e;
   {

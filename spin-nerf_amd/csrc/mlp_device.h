@@ -425,18 +425,28 @@ __device__ __forceinline__ void store16_stream(const char* sbase, uint32_t voff,
 }
 
 // frags [n*nt/NT, n*(nt+1)/NT) of an n-frag section tile (layout [frag][32 samples][32 B], odd frags
-// with the act_row swizzle): output tile nt's share of a stage's deferred stores
-template <int P, int N, int NT, class Frag>
+// with the act_row swizzle): output tile nt's share of a stage's deferred stores.
+// PAR = -1: every fragment; 0 / 1 (round 5): only the even / odd fragments, shared out over the NT tiles in the same way — a saved
+// layer's even fragments leave from the stage that PRODUCES them (fragment 2 nt right behind output tile nt's epilogue), its
+// odd fragments from the stage that consumes it, so that every stage issues one store per output tile instead of two per
+// tile in every other stage (SNR_STORE_SPLIT; the store path of a CU takes ~57 cycles per 1 KiB store: 72 % busy during a
+// storing stage, idle during the next).
+#ifndef SNR_STORE_SPLIT
+#define SNR_STORE_SPLIT 1
+#endif
+template <int P, int N, int NT, int PAR = -1, class Frag>
 __device__ __forceinline__ void store_tile_slice(const char* tile_base, const Frag* src, int nt, uint32_t lane_even, uint32_t lane_odd) {
-  static_for<0, N>([&](auto F_) {
-    constexpr int f = decltype(F_)::value;
+  constexpr int M = PAR < 0 ? N : (PAR == 0 ? (N + 1) / 2 : N / 2);   // fragments this call may store
+  static_for<0, M>([&](auto I_) {
+    constexpr int idx = decltype(I_)::value;
+    constexpr int f = PAR < 0 ? idx : 2 * idx + PAR;
     // (spread over the tiles 0.288 ms dgrad / 0.358 forward; whole section at once 0.300 / 0.371; two halves 0.295 / 0.364)
 #if defined(SNR_STORE_BURST) && SNR_STORE_BURST == 1     // A/B: the whole section behind the first output tile
     if (nt == 0)
 #elif defined(SNR_STORE_BURST) && SNR_STORE_BURST == 2   // A/B: in two halves
-    if ((nt == 0 && f < N / 2) || (nt == NT / 2 && f >= N / 2))
+    if ((nt == 0 && idx < M / 2) || (nt == NT / 2 && idx >= M / 2))
 #else
-    if (f >= N * nt / NT && f < N * (nt + 1) / NT)
+    if (idx >= M * nt / NT && idx < M * (nt + 1) / NT)
 #endif
       store16_stream<(f % 4) * 1024>(tile_base + (f / 4) * 4096, (f & 1) ? lane_odd : lane_even, src[f]);
   });

@@ -62,6 +62,8 @@ struct Tunables {
   int pair_poll, pair_lead;  // SNR_PAIR_POLL / SNR_PAIR_LEAD: pacing of the two kinds of a slot
   int only_kind, only_pair;  // SNR_PAIR_KIND / SNR_PAIR_PAIR (debug builds of the pair kernel only)
   int merge_nets;            // SNR_MERGE_NETS=0: one backward launch sequence per network (A/B against the merged one)
+  int chain_grid;            // SNR_CHAIN_GRID: workgroups of a chain-kernel launch (the rest grid-stride); 0 = default
+  int chain2;                // SNR_CHAIN2: the bf16 chain kernels with helper waves (mlp_chain2.h); 0 = the round-2 kernels (A/B)
 };
 inline Tunables read_tunables() {
   auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
@@ -77,6 +79,8 @@ inline Tunables read_tunables() {
   t.only_kind = geti("SNR_PAIR_KIND", -1);
   t.only_pair = geti("SNR_PAIR_PAIR", -1);
   t.merge_nets = geti("SNR_MERGE_NETS", 1);
+  t.chain2 = geti("SNR_CHAIN2", 0);
+  t.chain_grid = geti("SNR_CHAIN_GRID", 0);
   return t;
 }
 inline Tunables& tunables_storage() { static Tunables t = read_tunables(); return t; }   // (thread-safe initialisation)
