@@ -27,9 +27,10 @@
 extern "C" {
 #endif
 
-#define SNR_ABI_VERSION 3   /* 2: snr_mlp_backward / snr_pack_rays argument lists, snr_net / snr_step_state (round 2)
+#define SNR_ABI_VERSION 4   /* 2: snr_mlp_backward / snr_pack_rays argument lists, snr_net / snr_step_state (round 2)
                              * 3: snr_mlp_backward_multi, snr_adam_pack_multi, snr_render_step_prepare, snr_render_config.flags,
-                             *    snr_render_ws_layout.bwd_ws0, snr_tunables_reload (round 4) */
+                             *    snr_render_ws_layout.bwd_ws0, snr_tunables_reload (round 4)
+                             * 4: snr_render_rays_fused_forward_terms, snr_loss_terms, SNR_RENDER_LOSS4 (round 5) */
 
 #define SNR_OK 0
 #define SNR_ERR_NULL (-1)         /* a required pointer is NULL */
@@ -251,6 +252,7 @@ typedef struct snr_render_config {
 } snr_render_config;
 #define SNR_RENDER_Z_COARSE_READY 1  /* the workspace already holds the stratified z_vals of the coarse samples
                                         (snr_render_step_prepare wrote them): the forward does not sample them again */
+#define SNR_RENDER_LOSS4 2           /* snr_render_step_prepare zero-fills the four loss slots of a forward with loss terms */
 /* byte offsets inside the workspace of the tensors render_rays returns in its dict (run_nerf.py:715-726) and of the
  * intermediates the backward consumes; -1 = absent in this configuration */
 typedef struct snr_render_ws_layout {
@@ -277,6 +279,38 @@ int snr_render_rays_fused_forward(const snr_render_config* cfg, const snr_net* c
                                   const uint64_t* offset_base, const float* target, int64_t n_rays_global, void* ws, float* rgb_map, float* disp_map,
                                   float* acc_map, float* depth_map, float* rgb0, float* disp0, float* acc0, float* z_std,
                                   float* loss, snr_stream_t stream);
+/* The same call with the loss as a LIST OF TERMS over ray ranges (round 5: the SPIn-NeRF iteration, run_nerf.py:1455-1521, as
+ * one launch sequence — its three renders are one render of the concatenated rays, and its loss is
+ *   mse(rgb, target_clf) + mse(rgb0, target_clf)                         rays of the unmasked pixels     SNR_LOSS_RGB
+ *   mse(rgb, target_s) + mse(rgb0, target_s), detach_weights=True        rays of all pixels              SNR_LOSS_RGB_DETACHED
+ *   MSE(disp, depth_inp) + MSE(disp0, depth_inp), dropped when NaN       rays with an inpainted depth    SNR_LOSS_DISP, guarded).
+ * A term covers rays [first_ray, first_ray + n_rays); its mean runs over `count` rays (the GLOBAL batch of a data-parallel
+ * step); both passes add their part to loss[slot], the final pass also to loss[slot_final] (-1: nowhere).  Rays no term
+ * covers get no gradient.  guard_term >= 0 names a term with slot != 0 that follows run_nerf.py:1518-1521: once both passes
+ * have run, a NaN in loss[slot] zeroes that term's rays in the workspace's d raw tensors (the term and its gradient are
+ * dropped), otherwise loss[0] += loss[slot].  `loss` has 4 slots, zeroed by the caller (snr_render_step_prepare with
+ * SNR_RENDER_LOSS4 in cfg->flags does it). */
+#define SNR_LOSS_RGB 0
+#define SNR_LOSS_RGB_DETACHED 1
+#define SNR_LOSS_DISP 2
+typedef struct snr_loss_term {
+  int64_t first_ray, n_rays;
+  int kind;              /* SNR_LOSS_* */
+  const float* target;   /* [n_rays, 3] (rgb kinds) or [n_rays] (disparity), device memory */
+  int64_t count;         /* rays in the term's mean */
+  int slot, slot_final;
+} snr_loss_term;
+typedef struct snr_loss_terms {
+  int n_terms;           /* 1..4 */
+  snr_loss_term term[4];
+  int guard_term;        /* -1 or the index of the NaN-guarded term */
+} snr_loss_terms;
+int snr_render_rays_fused_forward_terms(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine,
+                                        const float* rays, int ray_ld, int64_t n_rays, const float* t_rand, const float* u,
+                                        const float* noise0, const float* noise, uint64_t seed, uint64_t offset,
+                                        const uint64_t* offset_base, const snr_loss_terms* terms, void* ws, float* rgb_map,
+                                        float* disp_map, float* acc_map, float* depth_map, float* rgb0, float* disp0, float* acc0,
+                                        float* z_std, float* loss, snr_stream_t stream);
 /* The head of a training step as ONE launch (pack_rays + stratified sampling + the zero fill of the loss accumulator were
  * three): the packed ray rows of render(rays=...)'s plain case (run_nerf.py:117-153: no c2w_staticcam, scalar near / far, no
  * depth column), the stratified z_vals of the coarse samples (run_nerf.py:646-668; t_rand [n, n_samples] when non-NULL, else

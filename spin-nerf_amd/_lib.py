@@ -48,6 +48,18 @@ class RenderWsLayout(_c.Structure):  # snr_render_ws_layout
                                   "d_raw", "act0", "act", "bwd_ws", "bwd_ws0", "total")]
 
 
+class LossTerm(_c.Structure):       # snr_loss_term
+    _fields_ = [("first_ray", _l), ("n_rays", _l), ("kind", _i), ("target", _p), ("count", _l), ("slot", _i), ("slot_final", _i)]
+
+
+class LossTerms(_c.Structure):      # snr_loss_terms
+    _fields_ = [("n_terms", _i), ("term", LossTerm * 4), ("guard_term", _i)]
+
+
+LOSS_RGB, LOSS_RGB_DETACHED, LOSS_DISP = 0, 1, 2
+RENDER_Z_COARSE_READY, RENDER_LOSS4 = 1, 2
+
+
 class StepState(_c.Structure):      # snr_step_state
     _fields_ = [("offset_base", _c.c_uint64), ("opt_step", _l), ("global_step", _l), ("lr", _f), ("bc1", _f),
                 ("bc2_sqrt", _f), ("reserved", _f)]
@@ -99,6 +111,8 @@ SIGNATURES = {
     "snr_step_state_advance": (_i, [_p, _c.c_double, _c.c_double, _f, _f, _c.c_uint64, _p]),
     "snr_render_rays_fused_forward": (_i, [_RCFG, _NET, _NET, _p, _i, _l, _p, _p, _p, _p, _c.c_uint64, _c.c_uint64, _p, _p, _l,
                                            _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "snr_render_rays_fused_forward_terms": (_i, [_RCFG, _NET, _NET, _p, _i, _l, _p, _p, _p, _p, _c.c_uint64, _c.c_uint64, _p,
+                                                 _c.POINTER(LossTerms), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "snr_render_step_prepare": (_i, [_RCFG, _p, _p, _l, _i, _i, _f, _i, _f, _f, _i, _p, _i, _p, _c.c_uint64, _c.c_uint64, _p, _p, _p, _p]),
     "snr_render_rays_fused_backward": (_i, [_RCFG, _NET, _NET, _p, _i, _l, _p, _p, _p, _i, _i, _p]),
     "snr_make_rays": (_i, [_i, _i, _f, _c.POINTER(_f), _i, _i, _i, _i, _i, _f, _f, _i, _p, _i, _p]),
@@ -122,7 +136,7 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3   # include/spinnerf_hip.h: SNR_ABI_VERSION (bumped whenever a prototype or a shared struct changes)
+ABI_VERSION = 4   # include/spinnerf_hip.h: SNR_ABI_VERSION (bumped whenever a prototype or a shared struct changes)
 
 
 def load():

@@ -94,26 +94,48 @@ extern "C" int snr_render_rays_fused_layout(const snr_render_config* cfg, const 
   return layout(cfg, coarse, fine, n_rays, train, out);
 }
 
-extern "C" int snr_render_rays_fused_forward(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine,
-                                             const float* rays, int ray_ld, int64_t n_rays, const float* t_rand,
-                                             const float* u, const float* noise0, const float* noise, uint64_t seed,
-                                             uint64_t offset, const uint64_t* offset_base, const float* target, int64_t n_rays_global, void* ws,
-                                             float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* rgb0,
-                                             float* disp0, float* acc0, float* z_std, float* loss, snr_stream_t stream) {
+namespace {
+// terms == nullptr: inference.  (validated: ranges inside [0, n_rays), slots 0..3, targets present)
+int forward_impl(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine, const float* rays, int ray_ld,
+                 int64_t n_rays, const float* t_rand, const float* u, const float* noise0, const float* noise, uint64_t seed,
+                 uint64_t offset, const uint64_t* offset_base, const snr_loss_terms* terms, void* ws, float* rgb_map,
+                 float* disp_map, float* acc_map, float* depth_map, float* rgb0, float* disp0, float* acc0, float* z_std,
+                 float* loss, snr_stream_t stream) {
   snr_render_ws_layout L;
-  const int train = target != nullptr;
+  const int train = terms != nullptr;
   int st = layout(cfg, coarse, fine, n_rays, train, &L);
   if (st != SNR_OK) return st;
   if (!rays || !ws || !rgb_map || !disp_map || !acc_map || !depth_map) return SNR_ERR_NULL;
   const int Nc = cfg->n_samples, Nf = cfg->n_importance, S = Nc + Nf;
   if (Nf > 0 && (!rgb0 || !disp0 || !acc0 || !z_std)) return SNR_ERR_NULL;
-  if (train && (!loss || n_rays_global < n_rays)) return train && !loss ? SNR_ERR_NULL : SNR_ERR_SHAPE;
+  snr::LossSpec spec{};
+  if (train) {
+    if (!loss) return SNR_ERR_NULL;
+    if (terms->n_terms < 1 || terms->n_terms > 4 || terms->guard_term >= terms->n_terms) return SNR_ERR_SHAPE;
+    spec.n = terms->n_terms;
+    for (int k = 0; k < spec.n; ++k) {
+      const snr_loss_term& t = terms->term[k];
+      if (!t.target) return SNR_ERR_NULL;
+      if (t.first_ray < 0 || t.n_rays <= 0 || t.first_ray + t.n_rays > n_rays || t.count < t.n_rays || t.slot < 0 || t.slot > 3 ||
+          t.slot_final > 3 || t.kind < SNR_LOSS_RGB || t.kind > SNR_LOSS_DISP)
+        return SNR_ERR_SHAPE;
+      const float inv = t.kind == SNR_LOSS_DISP ? 1.f / (float)t.count : 1.f / (3.f * (float)t.count);
+      spec.t[k] = snr::LossTerm{t.first_ray, t.n_rays, t.kind, t.target, inv, t.slot, t.slot_final < 0 ? -1 : t.slot_final};
+    }
+    if (terms->guard_term >= 0 && terms->term[terms->guard_term].slot == 0) return SNR_ERR_SHAPE;
+  }
   const snr_net* f = fine ? fine : coarse;
   if (ray_ld < 8 + ((wants_viewdirs(coarse) || wants_viewdirs(f)) ? 3 : 0)) return SNR_ERR_SHAPE;
   char* w = (char*)ws;
   auto F = [&](int64_t off) { return (float*)(w + off); };
   const int C0 = out_ch(coarse), C1 = out_ch(f);
   const int last0 = Nf == 0;   // the coarse pass is the final one
+  auto guard = [&]() {         // run_nerf.py:1518-1521, behind the final pass
+    if (!train || terms->guard_term < 0) return (int)SNR_OK;
+    const snr_loss_term& t = terms->term[terms->guard_term];
+    return snr::loss_guard_impl(loss, t.slot, t.first_ray, t.n_rays, F(L.d_raw0), (int64_t)Nc * C0, last0 ? nullptr : F(L.d_raw),
+                                (int64_t)S * C1, stream);
+  };
 
   // ---- coarse pass (run_nerf.py:646-692) ----
   if (cfg->flags & SNR_RENDER_Z_COARSE_READY) st = SNR_OK;   // snr_render_step_prepare wrote the stratified z_vals
@@ -128,24 +150,28 @@ extern "C" int snr_render_rays_fused_forward(const snr_render_config* cfg, const
   float* m_depth = last0 ? depth_map : F(L.depth0);
   bool sampled = false;   // the hierarchical sampling ran inside the compositing launch
   if (train && !last0) {
-    // compositing + loss + its backward of the coarse samples AND hierarchical sampling + sort from the weights, one kernel
+    // compositing + loss + its backward of the coarse samples AND hierarchical sampling + sort from the weights, one kernel.
+    // It declines shapes it does not cover (SNR_ERR_UNSUPPORTED: Nc > 64, unaligned raw rows): only then the two-kernel route
+    // below takes over — any other status is a real error and is returned
     st = snr::composite_train_sample_impl(F(L.raw0), C0, F(L.z_coarse), rays, ray_ld, noise0, cfg->raw_noise_std, seed, offset + 2,
-                                          offset_base, n_rays, Nc, cfg->white_bkgd, 0, target, n_rays_global, m_rgb, m_disp, m_acc,
+                                          offset_base, n_rays, Nc, cfg->white_bkgd, spec, m_rgb, m_disp, m_acc,
                                           m_depth, F(L.weights0), F(L.d_raw0), loss, cfg->perturb ? u : nullptr,
                                           cfg->perturb && !u, offset + 3, Nf, F(L.z_vals), F(L.z_samples), z_std, stream);
+    if (st != SNR_OK && st != SNR_ERR_UNSUPPORTED) return st;
     sampled = st == SNR_OK;
   }
   if (sampled) {
   } else if (train) {
     st = snr::composite_train_impl(F(L.raw0), C0, F(L.z_coarse), rays, ray_ld, noise0, cfg->raw_noise_std, seed, offset + 2,
-                                   offset_base, n_rays, Nc, cfg->white_bkgd, 0, target, n_rays_global, m_rgb, m_disp, m_acc, m_depth, F(L.weights0),
-                             F(L.d_raw0), loss, last0 ? loss + 1 : nullptr, stream);
+                                   offset_base, n_rays, Nc, cfg->white_bkgd, spec, last0, m_rgb, m_disp, m_acc, m_depth,
+                                   F(L.weights0), F(L.d_raw0), loss, stream);
   } else {
     if (cfg->raw_noise_std > 0.f && !noise0) return SNR_ERR_UNSUPPORTED;   // inference renders without density noise
     st = snr_composite_forward(F(L.raw0), C0, F(L.z_coarse), rays, ray_ld, noise0, n_rays, Nc, cfg->white_bkgd, m_rgb, m_disp,
                                m_acc, m_depth, F(L.weights0), nullptr, stream);
   }
-  if (st != SNR_OK || last0) return st;
+  if (st != SNR_OK) return st;
+  if (last0) return guard();
 
   // ---- hierarchical sampling + fine pass (run_nerf.py:694-713) ----
   if (sampled) st = SNR_OK;
@@ -154,14 +180,46 @@ extern "C" int snr_render_rays_fused_forward(const snr_render_config* cfg, const
   if (st != SNR_OK) return st;
   st = net_forward(f, rays, ray_ld, F(L.z_vals), n_rays, S, F(L.raw), train ? w + L.act : nullptr, stream);
   if (st != SNR_OK) return st;
-  if (train)
-    return snr::composite_train_impl(F(L.raw), C1, F(L.z_vals), rays, ray_ld, noise, cfg->raw_noise_std, seed, offset + 4, offset_base,
-                                     n_rays, S,
-                               cfg->white_bkgd, 0, target, n_rays_global, rgb_map, disp_map, acc_map, depth_map, F(L.weights),
-                               F(L.d_raw), loss, loss + 1, stream);
+  if (train) {
+    st = snr::composite_train_impl(F(L.raw), C1, F(L.z_vals), rays, ray_ld, noise, cfg->raw_noise_std, seed, offset + 4, offset_base,
+                                   n_rays, S, cfg->white_bkgd, spec, 1, rgb_map, disp_map, acc_map, depth_map, F(L.weights),
+                                   F(L.d_raw), loss, stream);
+    return st != SNR_OK ? st : guard();
+  }
   if (cfg->raw_noise_std > 0.f && !noise) return SNR_ERR_UNSUPPORTED;
   return snr_composite_forward(F(L.raw), C1, F(L.z_vals), rays, ray_ld, noise, n_rays, S, cfg->white_bkgd, rgb_map, disp_map,
                                acc_map, depth_map, F(L.weights), nullptr, stream);
+}
+}  // namespace
+
+extern "C" int snr_render_rays_fused_forward(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine,
+                                             const float* rays, int ray_ld, int64_t n_rays, const float* t_rand,
+                                             const float* u, const float* noise0, const float* noise, uint64_t seed,
+                                             uint64_t offset, const uint64_t* offset_base, const float* target, int64_t n_rays_global, void* ws,
+                                             float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* rgb0,
+                                             float* disp0, float* acc0, float* z_std, float* loss, snr_stream_t stream) {
+  if (!target)
+    return forward_impl(cfg, coarse, fine, rays, ray_ld, n_rays, t_rand, u, noise0, noise, seed, offset, offset_base, nullptr, ws,
+                        rgb_map, disp_map, acc_map, depth_map, rgb0, disp0, acc0, z_std, loss, stream);
+  if (n_rays_global < n_rays) return SNR_ERR_SHAPE;
+  // one term: mse(rgb, target) + mse(rgb0, target) over the global batch into loss[0], the final map's part also into loss[1]
+  snr_loss_terms one{};
+  one.n_terms = 1;
+  one.term[0] = snr_loss_term{0, n_rays, SNR_LOSS_RGB, target, n_rays_global, 0, 1};
+  one.guard_term = -1;
+  return forward_impl(cfg, coarse, fine, rays, ray_ld, n_rays, t_rand, u, noise0, noise, seed, offset, offset_base, &one, ws,
+                      rgb_map, disp_map, acc_map, depth_map, rgb0, disp0, acc0, z_std, loss, stream);
+}
+
+extern "C" int snr_render_rays_fused_forward_terms(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine,
+                                                   const float* rays, int ray_ld, int64_t n_rays, const float* t_rand,
+                                                   const float* u, const float* noise0, const float* noise, uint64_t seed,
+                                                   uint64_t offset, const uint64_t* offset_base, const snr_loss_terms* terms, void* ws,
+                                                   float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* rgb0,
+                                                   float* disp0, float* acc0, float* z_std, float* loss, snr_stream_t stream) {
+  if (!terms) return SNR_ERR_NULL;
+  return forward_impl(cfg, coarse, fine, rays, ray_ld, n_rays, t_rand, u, noise0, noise, seed, offset, offset_base, terms, ws,
+                      rgb_map, disp_map, acc_map, depth_map, rgb0, disp0, acc0, z_std, loss, stream);
 }
 
 extern "C" int snr_render_rays_fused_backward(const snr_render_config* cfg, const snr_net* coarse, const snr_net* fine,
@@ -208,5 +266,5 @@ extern "C" int snr_render_step_prepare(const snr_render_config* cfg, const float
   if (cfg->n_samples < 2) return SNR_ERR_SHAPE;
   return snr::pack_rays_sample_impl(rays_o, rays_d, n_rays, H, W, focal, ndc, near, far, use_viewdirs, rays, ray_ld, cfg->n_samples,
                                     cfg->lindisp, cfg->perturb ? t_rand : nullptr, cfg->perturb && !t_rand, seed, offset + 1,
-                                    offset_base, z_coarse, loss, loss ? 2 : 0, stream);
+                                    offset_base, z_coarse, loss, loss ? ((cfg->flags & SNR_RENDER_LOSS4) ? 4 : 2) : 0, stream);
 }

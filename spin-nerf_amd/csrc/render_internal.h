@@ -11,17 +11,30 @@ int sample_coarse_rng_impl(const float* rays, int ld, int64_t n_rays, int N, int
 int sample_fine_rng_impl(const float* z_coarse, const float* weights, int64_t n_rays, int Nc, int Nf, uint64_t seed,
                          uint64_t offset, const uint64_t* base, float* z_out, float* z_samples, float* z_std,
                          snr_stream_t stream);
+// the loss terms of a training render (include/spinnerf_hip.h: snr_loss_terms), as the kernels take them: by value
+struct LossTerm { int64_t first, n; int kind; const float* target; float inv_count; int slot, slot_final; };
+struct LossSpec { int n; LossTerm t[4]; };
+// one term over rays [0, n_rays): mean((rgb - target)^2) over 3 * n_rays_global elements into loss[0] (and loss[1] from the final pass)
+inline LossSpec plain_rgb_loss(const float* target, int64_t n_rays, int64_t n_rays_global) {
+  LossSpec s{};
+  s.n = 1;
+  s.t[0] = LossTerm{0, n_rays, 0, target, 1.f / (3.f * (float)n_rays_global), 0, 1};
+  return s;
+}
 int composite_train_impl(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
                          float noise_std, uint64_t seed, uint64_t offset, const uint64_t* base, int64_t n_rays, int S,
-                         int white, int detach, const float* target, int64_t n_rays_global, float* rgb_map, float* disp_map,
-                         float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss, float* loss_also,
-                         snr_stream_t stream);
+                         int white, const LossSpec& spec, int final_pass, float* rgb_map, float* disp_map,
+                         float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss, snr_stream_t stream);
 int composite_train_sample_impl(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
                                 float noise_std, uint64_t seed, uint64_t offset, const uint64_t* base, int64_t n_rays, int Nc,
-                                int white, int detach, const float* target, int64_t n_rays_global, float* rgb_map, float* disp_map,
+                                int white, const LossSpec& spec, float* rgb_map, float* disp_map,
                                 float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss, const float* u,
                                 int use_rng_u, uint64_t offset_u, int Nf, float* z_out, float* z_samples, float* z_std,
                                 snr_stream_t stream);
+// behind the final pass of a render with a NaN-guarded term (run_nerf.py:1518-1521): loss[slot] NaN -> the term's rows of
+// both passes' d raw become 0 and the term is dropped; else loss[0] += loss[slot]
+int loss_guard_impl(float* loss, int slot, int64_t first_ray, int64_t n_rays, float* d_raw0, int64_t row0, float* d_raw,
+                    int64_t row1, snr_stream_t stream);
 int pack_rays_sample_impl(const float* rays_o, const float* rays_d, int64_t n_rays, int H, int W, float focal, int ndc, float near,
                           float far, int use_viewdirs, float* rays, int ld, int N, int lindisp, const float* t_rand, int use_rng,
                           uint64_t seed, uint64_t offset, const uint64_t* base, float* z_vals, float* zero, int n_zero,

@@ -315,16 +315,62 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
 // network's colour map with its gradient (img2mse, helpers:15; run_nerf.py:1482-1490), and the compositing backward —
 // render_rays' tail and autograd's head without the rgb / gradient round trip and two extra launches.  inv_count =
 // 1 / (3 * rays of the GLOBAL batch); loss[slot] += this call's term (atomics, one per workgroup).
+// the term a ray belongs to (-1: none — no loss, zero gradient), its target row and the loss gradient at the maps
+struct RayLoss { int term; float gr, gg, gb, gP; int detach; float err; };
+__device__ __forceinline__ int term_of(const LossSpec& sp, int64_t ray) {
+  int ti = -1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < sp.n && ray >= sp.t[k].first && ray < sp.t[k].first + sp.t[k].n) ti = k;
+  return ti;
+}
+// kind 0 / 1: mean((rgb - target)^2) (1: through detached weights, helpers:385); kind 2: mean((disp - target)^2)
+__device__ __forceinline__ RayLoss ray_loss(const LossSpec& sp, int64_t ray, float r, float g, float b, float disp) {
+  RayLoss L{term_of(sp, ray), 0.f, 0.f, 0.f, 0.f, 0, 0.f};
+  if (L.term < 0) return L;
+  const LossTerm& t = sp.t[L.term];
+  const int64_t rel = ray - t.first;
+  if (t.kind == 2) {
+    const float dd = disp - t.target[rel];
+    L.err = dd * dd * t.inv_count;
+    L.gP = 2.f * dd * t.inv_count;
+  } else {
+    const float dr = r - t.target[3 * rel], dg = g - t.target[3 * rel + 1], db = b - t.target[3 * rel + 2];
+    L.err = (dr * dr + dg * dg + db * db) * t.inv_count;
+    L.gr = 2.f * dr * t.inv_count; L.gg = 2.f * dg * t.inv_count; L.gb = 2.f * db * t.inv_count;
+    L.detach = t.kind == 1;
+  }
+  return L;
+}
+// per workgroup: the rays' (already scaled) errors into their terms' slots, one atomic per term present
+__device__ __forceinline__ void add_losses(const LossSpec& sp, int final_pass, float err, int term, float* loss, float* sq, int* st) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { sq[wv] = err; st[wv] = term; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    bool has[4] = {false, false, false, false};
+    for (int w = 0; w < kRaysPerBlock; ++w)
+      if (st[w] >= 0) { t[st[w]] += sq[w]; has[st[w]] = true; }
+    for (int k = 0; k < 4; ++k)
+      if (has[k]) {
+        atomicAdd(loss + sp.t[k].slot, t[k]);
+        if (final_pass && sp.t[k].slot_final >= 0) atomicAdd(loss + sp.t[k].slot_final, t[k]);
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void composite_train_kernel(
     const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
-    NoiseSrc ns, int64_t n_rays, int S, int white, int detach, const float* __restrict__ target, float inv_count,
+    NoiseSrc ns, int64_t n_rays, int S, int white, LossSpec spec, int final_pass,
     float* __restrict__ rgb_map, float* __restrict__ disp_map, float* __restrict__ acc_map,
-    float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, float* __restrict__ loss,
-    float* __restrict__ loss_also) {
+    float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, float* __restrict__ loss) {
   __shared__ float sq[kRaysPerBlock];
+  __shared__ int st[kRaysPerBlock];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
-  float e2 = 0.f;
+  float err = 0.f;
+  int term = -1;
   if (ray < n_rays) {
     const float* rd = rays + ray * ld + 3;
     const float dn = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
@@ -333,19 +379,12 @@ __global__ __launch_bounds__(256) void composite_train_kernel(
       rgb_map[3 * ray] = m.r; rgb_map[3 * ray + 1] = m.g; rgb_map[3 * ray + 2] = m.b;
       disp_map[ray] = m.disp; acc_map[ray] = m.acc; depth_map[ray] = m.depth;
     }
-    const float dr = m.r - target[3 * ray], dg = m.g - target[3 * ray + 1], db = m.b - target[3 * ray + 2];
-    e2 = dr * dr + dg * dg + db * db;
-    composite_bwd_ray(raw, C, z_vals + ray * S, dn, ns, ray, S, white, detach, 2.f * dr * inv_count, 2.f * dg * inv_count,
-                      2.f * db * inv_count, 0.f, 0.f, 0.f, nullptr, nullptr, d_raw, lane);
+    const RayLoss L = ray_loss(spec, ray, m.r, m.g, m.b, m.disp);
+    err = L.err; term = L.term;
+    composite_bwd_ray(raw, C, z_vals + ray * S, dn, ns, ray, S, white, L.detach, L.gr, L.gg, L.gb, 0.f, 0.f, L.gP, nullptr, nullptr,
+                      d_raw, lane);
   }
-  if (lane == 0) sq[wv] = e2;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int w = 0; w < kRaysPerBlock; ++w) t += sq[w];
-    atomicAdd(loss, t * inv_count);
-    if (loss_also) atomicAdd(loss_also, t * inv_count);
-  }
+  add_losses(spec, final_pass, err, term, loss, sq, st);
 }
 
 // The same kernel with the ray held in registers (S <= 64 * NCH): every global load of the ray is issued up front, the
@@ -358,7 +397,7 @@ __global__ __launch_bounds__(256) void composite_train_kernel(
 template <int NCH>
 __device__ __forceinline__ float composite_train_ray(
     const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
-    const NoiseSrc& ns, int64_t ray, int S, int white, int detach, const float* __restrict__ target, float inv_count,
+    const NoiseSrc& ns, int64_t ray, int S, int white, const LossSpec& spec, int& term,
     float* __restrict__ rgb_map, float* __restrict__ disp_map, float* __restrict__ acc_map,
     float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, int lane, float* w_keep) {
   float e2 = 0.f;
@@ -384,7 +423,6 @@ __device__ __forceinline__ float composite_train_ray(
         }
       }
     }
-    const float t0 = target[3 * ray], t1 = target[3 * ray + 1], t2 = target[3 * ray + 2];
     const float dn = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
     // ---- forward (composite_fwd_ray) ----
     float dist[NCH], c0[NCH], c1[NCH], c2[NCH], one_m[NCH], Ti[NCH], w[NCH];
@@ -419,16 +457,21 @@ __device__ __forceinline__ float composite_train_ray(
       rgb_map[3 * ray] = sr; rgb_map[3 * ray + 1] = sg; rgb_map[3 * ray + 2] = sb;
       disp_map[ray] = disp; acc_map[ray] = sa; depth_map[ray] = sd;
     }
-    // ---- loss gradient and backward (composite_bwd_ray with g_disp = g_acc = g_depth = 0) ----
-    const float dr = sr - t0, dg = sg - t1, db = sb - t2;
-    e2 = dr * dr + dg * dg + db * db;
-    const float gr = 2.f * dr * inv_count, gg = 2.f * dg * inv_count, gb = 2.f * db * inv_count;
+    // ---- loss gradient and backward (composite_bwd_ray with g_acc = g_depth = 0) ----
+    const RayLoss L = ray_loss(spec, ray, sr, sg, sb, disp);
+    term = L.term;
+    e2 = L.err;
+    const float gr = L.gr, gg = L.gg, gb = L.gb;
+    const int detach = L.detach;
     const float gwhite = white ? -(gr + gg + gb) : 0.f;
+    // the disparity term of composite_bwd_ray: exactly absent without a gradient into the disparity
+    const bool use_disp = L.gP != 0.f;
+    const float dq = (q > 1e-10f) ? -L.gP / (q * q) : ((q != q) ? q : 0.f);
     float suffix_next = 0.f;
 #pragma unroll
     for (int c = NCH - 1; c >= 0; --c) {
       const int i = 64 * c + lane;
-      float G = 0.f * z[c] + 0.f + gwhite + 0.f;
+      float G = 0.f * z[c] + 0.f + gwhite + (use_disp ? dq * (z[c] - q) / sa : 0.f);
       if (!detach) G += gr * c0[c] + gg * c1[c] + gb * c2[c];
       if (!in[c]) G = 0.f;
       const float Gw = G * w[c];
@@ -456,25 +499,19 @@ __device__ __forceinline__ float composite_train_ray(
 template <int NCH>
 __global__ __launch_bounds__(256) void composite_train_reg_kernel(
     const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
-    NoiseSrc ns, int64_t n_rays, int S, int white, int detach, const float* __restrict__ target, float inv_count,
+    NoiseSrc ns, int64_t n_rays, int S, int white, LossSpec spec, int final_pass,
     float* __restrict__ rgb_map, float* __restrict__ disp_map, float* __restrict__ acc_map,
-    float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, float* __restrict__ loss,
-    float* __restrict__ loss_also) {
+    float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, float* __restrict__ loss) {
   __shared__ float sq[kRaysPerBlock];
+  __shared__ int st[kRaysPerBlock];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
-  float e2 = 0.f;
+  float err = 0.f;
+  int term = -1;
   if (ray < n_rays)
-    e2 = composite_train_ray<NCH>(raw, C, z_vals, rays, ld, ns, ray, S, white, detach, target, inv_count, rgb_map, disp_map, acc_map,
-                                  depth_map, weights, d_raw, lane, nullptr);
-  if (lane == 0) sq[wv] = e2;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int k = 0; k < kRaysPerBlock; ++k) t += sq[k];
-    atomicAdd(loss, t * inv_count);
-    if (loss_also) atomicAdd(loss_also, t * inv_count);
-  }
+    err = composite_train_ray<NCH>(raw, C, z_vals, rays, ld, ns, ray, S, white, spec, term, rgb_map, disp_map, acc_map,
+                                   depth_map, weights, d_raw, lane, nullptr);
+  add_losses(spec, final_pass, err, term, loss, sq, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -587,33 +624,42 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
 // one launch (with its ramp: a wave per ray, 1024 rays) replaces two.  Nc <= 64.
 __global__ __launch_bounds__(256) void composite_train_sample_kernel(
     const float* __restrict__ raw, int C, const float* __restrict__ z_vals, const float* __restrict__ rays, int ld,
-    NoiseSrc ns, int64_t n_rays, int Nc, int white, int detach, const float* __restrict__ target, float inv_count,
+    NoiseSrc ns, int64_t n_rays, int Nc, int white, LossSpec spec,
     float* __restrict__ rgb_map, float* __restrict__ disp_map, float* __restrict__ acc_map,
     float* __restrict__ depth_map, float* __restrict__ weights, float* __restrict__ d_raw, float* __restrict__ loss,
     const float* __restrict__ u_in, int Nf, int npow2, float* __restrict__ z_out, float* __restrict__ z_samples,
     float* __restrict__ z_std, int use_rng, Rng rng) {
   extern __shared__ float lds[];
   __shared__ float sq[kRaysPerBlock];
+  __shared__ int st[kRaysPerBlock];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
   const int nb = Nc - 1;
   const int per_wave = Nc + 2 * nb + npow2;
   float* w_keep = lds + wv * per_wave;
-  float e2 = 0.f;
+  float err = 0.f;
+  int term = -1;
   if (ray < n_rays) {
-    e2 = composite_train_ray<1>(raw, C, z_vals, rays, ld, ns, ray, Nc, white, detach, target, inv_count, rgb_map, disp_map, acc_map,
-                                depth_map, weights, d_raw, lane, w_keep);
+    err = composite_train_ray<1>(raw, C, z_vals, rays, ld, ns, ray, Nc, white, spec, term, rgb_map, disp_map, acc_map,
+                                 depth_map, weights, d_raw, lane, w_keep);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     sample_fine_ray(z_vals + ray * Nc, w_keep, u_in, ray, Nc, Nf, npow2, z_out, z_samples, z_std, 0, use_rng, rng, w_keep + Nc, lane);
   }
-  if (lane == 0) sq[wv] = e2;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int k = 0; k < kRaysPerBlock; ++k) t += sq[k];
-    atomicAdd(loss, t * inv_count);
+  add_losses(spec, 0, err, term, loss, sq, st);
+}
+
+// the NaN guard of a loss term (run_nerf.py:1518-1521): see render_internal.h: loss_guard_impl
+__global__ void loss_guard_kernel(float* __restrict__ loss, int slot, float* __restrict__ d0, int64_t n0, float* __restrict__ d1,
+                                  int64_t n1) {
+  const float v = loss[slot];
+  const bool bad = v != v;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (bad) {
+    if (d0 && i < n0) d0[i] = 0.f;
+    if (d1 && i < n1) d1[i] = 0.f;
   }
+  if (i == 0 && !bad) loss[0] += v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1026,12 +1072,12 @@ extern "C" int snr_sample_fine_rng(const float* z_coarse, const float* weights, 
 
 int snr::composite_train_impl(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
                               float noise_std, uint64_t seed, uint64_t offset, const uint64_t* base, int64_t n_rays, int S,
-                              int white, int detach, const float* target, int64_t n_rays_global, float* rgb_map,
+                              int white, const LossSpec& spec, int final_pass, float* rgb_map,
                               float* disp_map, float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss,
-                              float* loss_also, snr_stream_t stream) {
-  SNR_CHECK_ARG(raw && z && rays && target && rgb_map && disp_map && acc_map && depth_map && weights && d_raw && loss,
-                SNR_ERR_NULL);
-  SNR_CHECK_ARG(n_rays > 0 && n_rays_global >= n_rays && S > 0 && C >= 4 && ld >= 6, SNR_ERR_SHAPE);
+                              snr_stream_t stream) {
+  SNR_CHECK_ARG(raw && z && rays && rgb_map && disp_map && acc_map && depth_map && weights && d_raw && loss, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_rays > 0 && S > 0 && C >= 4 && ld >= 6 && spec.n >= 0 && spec.n <= 4, SNR_ERR_SHAPE);
+  for (int k = 0; k < spec.n; ++k) SNR_CHECK_ARG(spec.t[k].target, SNR_ERR_NULL);
   const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   const NoiseSrc ns{noise, (!noise && noise_std > 0.f) ? 1 : 0, make_rng(seed, offset, base), noise_std};
   {
@@ -1039,9 +1085,7 @@ int snr::composite_train_impl(const float* raw, int C, const float* z, const flo
     // 16-byte raw rows (C == 4) need 16-byte aligned bases for the vector accesses of the register-resident version
     const bool aligned = C != 4 || ((((uintptr_t)raw) | ((uintptr_t)d_raw)) & 15) == 0;
     ProfScope ps(nch <= 4 && aligned ? K_COMPOSITE_TRAIN_REG : K_COMPOSITE_TRAIN, (hipStream_t)stream);
-    const float inv_count = 1.f / (3.f * (float)n_rays_global);
-#define SNR_CT_ARGS raw, C, z, rays, ld, ns, n_rays, S, white, detach, target, inv_count, rgb_map, disp_map, acc_map, depth_map, \
-                    weights, d_raw, loss, loss_also
+#define SNR_CT_ARGS raw, C, z, rays, ld, ns, n_rays, S, white, spec, final_pass, rgb_map, disp_map, acc_map, depth_map, weights, d_raw, loss
     if (nch == 1 && aligned) composite_train_reg_kernel<1><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(SNR_CT_ARGS);
     else if (nch == 2 && aligned) composite_train_reg_kernel<2><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(SNR_CT_ARGS);
     else if (nch == 3 && aligned) composite_train_reg_kernel<3><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(SNR_CT_ARGS);
@@ -1054,13 +1098,14 @@ int snr::composite_train_impl(const float* raw, int C, const float* z, const flo
 // composite_train of the coarse samples + hierarchical sampling from its weights, one kernel (Nc <= 64, 16-byte aligned raw rows)
 int snr::composite_train_sample_impl(const float* raw, int C, const float* z, const float* rays, int ld, const float* noise,
                                      float noise_std, uint64_t seed, uint64_t offset, const uint64_t* base, int64_t n_rays, int Nc,
-                                     int white, int detach, const float* target, int64_t n_rays_global, float* rgb_map,
+                                     int white, const LossSpec& spec, float* rgb_map,
                                      float* disp_map, float* acc_map, float* depth_map, float* weights, float* d_raw, float* loss,
                                      const float* u, int use_rng_u, uint64_t offset_u, int Nf, float* z_out, float* z_samples,
                                      float* z_std, snr_stream_t stream) {
-  SNR_CHECK_ARG(raw && z && rays && target && rgb_map && disp_map && acc_map && depth_map && weights && d_raw && loss && z_out,
+  SNR_CHECK_ARG(raw && z && rays && rgb_map && disp_map && acc_map && depth_map && weights && d_raw && loss && z_out,
                 SNR_ERR_NULL);
-  SNR_CHECK_ARG(n_rays > 0 && n_rays_global >= n_rays && Nc >= 3 && Nc <= kWave && Nf >= 1 && C >= 4 && ld >= 6, SNR_ERR_SHAPE);
+  SNR_CHECK_ARG(n_rays > 0 && Nc >= 3 && Nc <= kWave && Nf >= 1 && C >= 4 && ld >= 6 && spec.n >= 0 && spec.n <= 4, SNR_ERR_SHAPE);
+  for (int k = 0; k < spec.n; ++k) SNR_CHECK_ARG(spec.t[k].target, SNR_ERR_NULL);
   if (C == 4 && ((((uintptr_t)raw) | ((uintptr_t)d_raw)) & 15) != 0) return SNR_ERR_UNSUPPORTED;
   int npow2 = 2;
   while (npow2 < Nc + Nf) npow2 <<= 1;
@@ -1071,9 +1116,20 @@ int snr::composite_train_sample_impl(const float* raw, int C, const float* z, co
   {
     ProfScope ps(K_COMPOSITE_TRAIN_SAMPLE, (hipStream_t)stream);
     composite_train_sample_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(
-        raw, C, z, rays, ld, ns, n_rays, Nc, white, detach, target, 1.f / (3.f * (float)n_rays_global), rgb_map, disp_map, acc_map,
+        raw, C, z, rays, ld, ns, n_rays, Nc, white, spec, rgb_map, disp_map, acc_map,
         depth_map, weights, d_raw, loss, u, Nf, npow2, z_out, z_samples, z_std, use_rng_u, make_rng(seed, offset_u, base));
   }
+  return launch_status();
+}
+
+int snr::loss_guard_impl(float* loss, int slot, int64_t first_ray, int64_t n_rays, float* d_raw0, int64_t row0, float* d_raw,
+                         int64_t row1, snr_stream_t stream) {
+  SNR_CHECK_ARG(loss, SNR_ERR_NULL);
+  SNR_CHECK_ARG(slot > 0 && slot < 4 && first_ray >= 0 && n_rays > 0, SNR_ERR_SHAPE);
+  const int64_t n0 = d_raw0 ? n_rays * row0 : 0, n1 = d_raw ? n_rays * row1 : 0;
+  const int64_t n = n0 > n1 ? n0 : n1;
+  loss_guard_kernel<<<dim3((unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1)), dim3(256), 0, (hipStream_t)stream>>>(
+      loss, slot, d_raw0 ? d_raw0 + first_ray * row0 : nullptr, n0, d_raw ? d_raw + first_ray * row1 : nullptr, n1);
   return launch_status();
 }
 
@@ -1098,8 +1154,18 @@ extern "C" int snr_composite_train(const float* raw, int C, const float* z, cons
                                    int detach, const float* target, int64_t n_rays_global, float* rgb_map,
                                    float* disp_map, float* acc_map, float* depth_map, float* weights, float* d_raw,
                                    float* loss, float* loss_also, snr_stream_t stream) {
-  return snr::composite_train_impl(raw, C, z, rays, ld, noise, noise_std, seed, offset, nullptr, n_rays, S, white, detach, target,
-                                   n_rays_global, rgb_map, disp_map, acc_map, depth_map, weights, d_raw, loss, loss_also, stream);
+  SNR_CHECK_ARG(target && loss, SNR_ERR_NULL);
+  SNR_CHECK_ARG(n_rays > 0 && n_rays_global >= n_rays, SNR_ERR_SHAPE);
+  // the kernels address their accumulators as slots of one 4-float block: `loss` and `loss_also` must lie within one
+  float* base = (loss_also && loss_also < loss) ? loss_also : loss;
+  const int64_t s0 = loss - base, s1 = loss_also ? loss_also - base : -1;
+  if (s0 > 3 || s1 > 3) return SNR_ERR_UNSUPPORTED;
+  snr::LossSpec sp = snr::plain_rgb_loss(target, n_rays, n_rays_global);
+  sp.t[0].kind = detach ? 1 : 0;
+  sp.t[0].slot = (int)s0;
+  sp.t[0].slot_final = (int)s1;
+  return snr::composite_train_impl(raw, C, z, rays, ld, noise, noise_std, seed, offset, nullptr, n_rays, S, white, sp, 1, rgb_map,
+                                   disp_map, acc_map, depth_map, weights, d_raw, base, stream);
 }
 
 extern "C" int snr_make_rays(int H, int W, float focal, const float* c2w_host, int i0, int j0, int h, int w, int ndc,

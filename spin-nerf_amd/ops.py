@@ -482,7 +482,7 @@ def _net_struct(net):
 
 
 def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bkgd, perturb, raw_noise_std, seed, offset,
-                  target, loss, n_rays_global=None, randoms=None, offset_base=None, prepare=None):
+                  target, loss, n_rays_global=None, randoms=None, offset_base=None, prepare=None, loss_terms=None, guard_term=-1):
     """render_rays + the loss terms + the compositing backward of one training step in one library call.  ``net_f`` None
     with N_importance > 0 = the coarse network evaluated twice.  Consumes the Philox offsets offset+1 .. offset+4.
     Returns a FusedRender; fused_backward(handle) gives the parameter gradients.  ``target`` None (and ``loss`` None) =
@@ -490,7 +490,10 @@ def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bk
     first field is added to the draw offsets at run time: graph replays).
     ``prepare`` = dict(rays_o, rays_d, H, W, focal, ndc, near, far, use_viewdirs) instead of packed ``rays``: the packed rows,
     the stratified z_vals and the zero fill of ``loss`` are made by ONE launch (snr_render_step_prepare) in front of the
-    forward; the rows are in the returned handle (``.rays``)."""
+    forward; the rows are in the returned handle (``.rays``).
+    ``loss_terms`` (instead of ``target``) = list of dicts(first, n, kind, target, count=None, slot, slot_final=-1): the loss as
+    terms over ray ranges (snr_render_rays_fused_forward_terms; kinds _lib.LOSS_*), ``guard_term`` the index of the NaN-guarded
+    one; ``loss`` then has 4 slots (zeroed by the prepare launch, or by the caller)."""
     import ctypes
     lib = _lib.load()
     rnd = randoms or {}
@@ -499,14 +502,16 @@ def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bk
         n = ro.shape[0]
         rays = torch.empty(n, 11 if prepare["use_viewdirs"] else 8, device=ro.device, dtype=torch.float32)
     n = rays.shape[0]
+    flags = (_lib.RENDER_Z_COARSE_READY if prepare is not None else 0) | (_lib.RENDER_LOSS4 if loss_terms is not None else 0)
     rc = _lib.RenderConfig(int(N_samples), int(N_importance), int(bool(lindisp)), int(bool(white_bkgd)),
-                           int(perturb > 0.), float(raw_noise_std), 1 if prepare is not None else 0)
+                           int(perturb > 0.), float(raw_noise_std), flags)
+    train = target is not None or loss_terms is not None
     sc, pc = _net_struct(net_c)
     two = N_importance > 0 and net_f is not None and net_f is not net_c
     sf, pf = _net_struct(net_f) if two else (None, None)
     L = _lib.RenderWsLayout()
     fptr = ctypes.byref(sf) if two else None
-    check(lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(sc), fptr, n, int(target is not None), ctypes.byref(L)),
+    check(lib.snr_render_rays_fused_layout(ctypes.byref(rc), ctypes.byref(sc), fptr, n, int(train), ctypes.byref(L)),
           "snr_render_rays_fused_layout")
     dev = rays.device
     ws = torch.empty(L.total, device=dev, dtype=torch.uint8)
@@ -522,6 +527,22 @@ def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bk
                                           float(prepare["far"]), int(bool(prepare["use_viewdirs"])), ptr(rays), rays.shape[1],
                                           ptr(arr["t_rand"]), int(seed), int(offset), ptr(offset_base), ptr(z_coarse), ptr(loss),
                                           stream()), "snr_render_step_prepare")
+    if loss_terms is not None:
+        lt = _lib.LossTerms()
+        lt.n_terms, lt.guard_term = len(loss_terms), int(guard_term)
+        keep = []
+        for k, t in enumerate(loss_terms):
+            tg = f32c(t["target"])
+            keep.append(tg)
+            lt.term[k] = _lib.LossTerm(int(t["first"]), int(t["n"]), int(t["kind"]), tg.data_ptr(),
+                                       int(t.get("count") or t["n"]), int(t["slot"]), int(t.get("slot_final", -1)))
+        arr["_targets"] = keep
+        check(lib.snr_render_rays_fused_forward_terms(
+            ctypes.byref(rc), ctypes.byref(sc), fptr, ptr(rays), rays.shape[1], n, ptr(arr["t_rand"]), ptr(arr["u"]),
+            ptr(arr["noise_c"]), ptr(arr["noise_f"]), int(seed), int(offset), ptr(offset_base), ctypes.byref(lt), ptr(ws),
+            ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(rgb0), ptr(disp0), ptr(acc0), ptr(z_std), ptr(loss), stream()),
+            "snr_render_rays_fused_forward_terms")
+        return FusedRender(rc, (sc, sf), (pc, pf, arr), rays, n, ws, L, (rgb, disp, acc, depth, rgb0, disp0, acc0, z_std), loss)
     check(lib.snr_render_rays_fused_forward(
         ctypes.byref(rc), ctypes.byref(sc), fptr, ptr(rays), rays.shape[1], n, ptr(arr["t_rand"]), ptr(arr["u"]),
         ptr(arr["noise_c"]), ptr(arr["noise_f"]), int(seed), int(offset), ptr(offset_base), ptr(target),

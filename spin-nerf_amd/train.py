@@ -462,8 +462,76 @@ class RenderTrainer:
             write_png(os.path.join(out_dir, "label", f"img{i:03d}.png"), np.clip(np.rint(m), 0, 255).astype(np.uint8))
         return disps
 
+    def _spin_direct(self, H, W, focal, batch_rays_clf, target_clf, batch_rays, target_s, batch_inp, depth_inp, randoms=None):
+        """The three renders of the iteration as ONE render of the concatenated rays (rays are independent), on the step's
+        library route: snr_render_step_prepare, snr_render_rays_fused_forward_terms — the loss as three terms over the three ray
+        ranges (unmasked pixels: rgb; all pixels: rgb through detached weights; inpainted-depth rays: disparity, NaN-guarded
+        like run_nerf.py:1518-1521) —, ONE backward launch sequence over all rays for both networks, snr_adam_pack_multi.  No
+        torch autograd; the sum of the three terms' gradients is what one backward over the concatenated batch computes."""
+        kw = self.kw
+        Nc, Nf = kw['N_samples'], kw.get('N_importance', 0)
+        net_c = kw['network_fn']
+        net_f = (kw.get('network_fine') or net_c) if Nf > 0 else None
+        two = Nf > 0 and net_f is not net_c
+        n1, n2, n3 = batch_rays_clf.shape[1], batch_rays.shape[1], batch_inp.shape[1]
+        rays_all = torch.cat([batch_rays_clf, batch_rays, batch_inp], 1)
+        rnd = None
+        if randoms and all(r is not None for r in randoms[:3]):
+            rnd = {k: torch.cat([ops.f32c(r[k]) for r in randoms[:3]], 0) for k in randoms[0]}
+        loss = torch.empty(4, device=rays_all.device)   # [0] the iteration's loss, [1] mse(rgb, target_clf) alone, [2] the geometry term
+        prep = dict(rays_o=rays_all[0], rays_d=rays_all[1], H=H, W=W, focal=focal, ndc=kw.get('ndc', True),
+                    near=float(kw.get('near', 0.)), far=float(kw.get('far', 1.)), use_viewdirs=kw.get('use_viewdirs', False))
+        terms = [dict(first=0, n=n1, kind=_lib.LOSS_RGB, target=target_clf, slot=0, slot_final=1),
+                 dict(first=n1, n=n2, kind=_lib.LOSS_RGB_DETACHED, target=target_s, slot=0),
+                 dict(first=n1 + n2, n=n3, kind=_lib.LOSS_DISP, target=depth_inp, slot=2)]
+        h = ops.fused_forward(net_c, net_f if two else None, None, Nc, Nf, kw.get('lindisp', False), kw.get('white_bkgd', False),
+                              kw.get('perturb', 0.), float(kw.get('raw_noise_std', 0.)), self._seed, self._draws, None, loss,
+                              randoms=rnd, prepare=prep, loss_terms=terms, guard_term=2)
+        self._draws += 4
+        if two:
+            n_c = net_c.flat.numel()
+            g_both = torch.empty(n_c + net_f.flat.numel(), device=net_c.flat.device, dtype=net_c.flat.dtype)
+            g_c, g_f = g_both[:n_c], g_both[n_c:]
+            ops.fused_backward(h, g_c, g_f)
+            net_f.flat.grad = g_f
+            net_c.flat.grad = g_c
+            if self.world_size > 1 and os.environ.get("SNR_SPLIT_ALLREDUCE") != "1":
+                import torch.distributed as dist
+                work = dist.all_reduce(g_both, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                self._works[self.nets.index(net_c)] = self._works[self.nets.index(net_f)] = work
+        else:
+            g_c = torch.empty_like(net_c.flat.data)
+            ops.fused_backward(h, g_c)
+            net_c.flat.grad = g_c
+        self.apply_gradients()
+        self._last_spin = h
+        return loss[0], -10.0 * torch.log10(loss[1])
+
+    def _spin_direct_ok(self, args, kwargs):
+        if os.environ.get("SNR_NO_FUSED_STEP") == "1" or os.environ.get("SNR_NO_DIRECT_SPIN") == "1":
+            return False
+        names = ("H", "W", "focal", "batch_rays_clf", "target_clf", "batch_rays", "target_s", "batch_inp", "depth_inp")
+        a = dict(zip(names, args))
+        a.update(kwargs)
+        if set(a) - set(names) - {"randoms", "chunk", "batched"} or a.get("batch_inp") is None or a.get("depth_inp") is None:
+            return False      # COLMAP-depth render, LPIPS term, no geometry term: the general route
+        n = a["batch_rays_clf"].shape[1] + a["batch_rays"].shape[1] + a["batch_inp"].shape[1]
+        if not self._direct_ok(a["batch_rays_clf"], n, {}) or n > a.get("chunk", 1024 * 32) * 3:
+            return False
+        from .nerf import NeRF
+        kw = self.kw
+        nets = [kw.get('network_fn')] + ([kw['network_fine']] if kw.get('N_importance', 0) > 0 and kw.get('network_fine') is not None else [])
+        return all(type(x) is NeRF for x in nets)
+
     def spin_iteration(self, *args, **kwargs):
-        """spin_loss + backward + all-reduce + Adam; returns (loss, psnr of the unmasked-pixel render)."""
+        """spin_loss + backward + all-reduce + Adam; returns (loss, psnr of the unmasked-pixel render).  The default
+        iteration (three renders, MLP networks, no COLMAP-depth / LPIPS term) takes the step's library route without torch
+        autograd (_spin_direct); everything else, or SNR_NO_DIRECT_SPIN=1, goes through spin_loss + autograd."""
+        if self._spin_direct_ok(args, kwargs):
+            names = ("H", "W", "focal", "batch_rays_clf", "target_clf", "batch_rays", "target_s", "batch_inp", "depth_inp")
+            a = dict(zip(names, args))
+            a.update({k: v for k, v in kwargs.items() if k in names or k == "randoms"})
+            return self._spin_direct(**a)
         for n in self.nets:
             n.flat.grad = None
         loss, outs = self.spin_loss(*args, **kwargs)

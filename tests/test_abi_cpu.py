@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(S):
 
 def test_size_queries_and_validation_run_on_host(S):
     lib = S._lib.load()
-    assert lib.snr_abi_version() == 3 == S._lib.ABI_VERSION
+    assert lib.snr_abi_version() == 4 == S._lib.ABI_VERSION
     cfg = S._lib.MlpConfig(10, 4, 0, 1, 4, S._lib.PREC_BF16)
     assert lib.snr_mlp_param_count(cfg) == 595844          # SURVEY.md §8 a6 [measured]
     assert lib.snr_mlp_packed_bytes(cfg) > 2 * 595844 * 2  # forward + transposed copies, bf16

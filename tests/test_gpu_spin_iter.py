@@ -95,6 +95,159 @@ def test_spin_iteration_loss_and_gradients_match_oracle():
     assert np.isfinite(float(l3))
 
 
+def _spin_setup(precision="fp32", N=40, Nc=64, Nf=32, gain=1.0):
+    import spin_nerf_amd as S
+    train = importlib.import_module("spin-nerf_amd.train")
+    H, W, focal, near, far = 20, 24, 30.0, 2.0, 6.0
+    sd_c = O.init_nerf_params(seed=3, gain=gain) if gain != 1.0 else O.init_nerf_params(seed=3)
+    sd_f = O.init_nerf_params(seed=4, gain=gain) if gain != 1.0 else O.init_nerf_params(seed=4)
+
+    def mk(sd):
+        n = S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True, precision=precision).cuda()
+        n.load_state_dict(sd)
+        return n
+    net_c, net_f = mk(sd_c), mk(sd_f)
+
+    def q(inputs, viewdirs, network_fn):
+        return S.run_network(inputs, viewdirs, network_fn)
+    q._snr_fused = True
+    kw = dict(network_query_fn=q, perturb=1.0, N_importance=Nf, network_fine=net_f, N_samples=Nc, network_fn=net_c,
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=1.0, ndc=False, lindisp=False, near=near, far=far)
+    tr = train.RenderTrainer(kw, lrate=5e-4)
+    g = torch.Generator().manual_seed(0)
+    c2w = torch.eye(4)[:3, :4].clone(); c2w[2, 3] = 4.0
+    ro, rd = O.get_rays(H, W, focal, c2w)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+
+    def batch():
+        sel = torch.randperm(H * W, generator=g)[:N]
+        return torch.stack([ro[sel], rd[sel]], 0)
+    rays = [batch(), batch(), batch()]
+    t_clf, t_all = torch.rand(N, 3, generator=g), torch.rand(N, 3, generator=g)
+    d_inp = torch.rand(N, generator=g) * 0.3 + 0.1
+
+    def rnd(seed):
+        gg = torch.Generator().manual_seed(seed)
+        return {"t_rand": torch.rand(N, Nc, generator=gg), "u": torch.rand(N, Nf, generator=gg),
+                "noise_c": torch.randn(N, Nc, generator=gg), "noise_f": torch.randn(N, Nc + Nf, generator=gg)}
+    rnds = [rnd(1), rnd(2), rnd(3)]
+    return dict(S=S, tr=tr, nets=(net_c, net_f), sd=(sd_c, sd_f), hwf=(H, W, focal), near=near, far=far, Nc=Nc, Nf=Nf, N=N,
+                rays=rays, t_clf=t_clf, t_all=t_all, d_inp=d_inp, rnds=rnds)
+
+
+def test_direct_spin_iteration_matches_oracle_and_the_autograd_route(monkeypatch):
+    """Round 5: the iteration on the step's library route (RenderTrainer._spin_direct: one render of the concatenated rays
+    with the loss as three terms, one backward launch sequence, no torch autograd) — loss and parameter gradients against the
+    oracle's three renders (the gates of the autograd-route test above), against the autograd route itself, and the NaN guard
+    of the geometry term (run_nerf.py:1518-1521)."""
+    c = _spin_setup()
+    tr, (net_c, net_f), (sd_c, sd_f) = c["tr"], c["nets"], c["sd"]
+    H, W, focal = c["hwf"]
+    cu = lambda t: t.cuda()
+    rays, rnds = c["rays"], c["rnds"]
+    curnd = [{k: cu(v) for k, v in r.items()} for r in rnds]
+    args = (H, W, focal, cu(rays[0]), cu(c["t_clf"]), cu(rays[1]), cu(c["t_all"]), cu(rays[2]), cu(c["d_inp"]))
+
+    # ---- oracle ----
+    pc = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in sd_f.items()}
+    okw = dict(sd_coarse=pc, sd_fine=pf, N_samples=c["Nc"], N_importance=c["Nf"], perturb=1.0, white_bkgd=False, lindisp=False,
+               use_viewdirs=True, ndc=False, near=c["near"], far=c["far"], retraw=True)
+    rgb, disp, acc, depth, ex = O.render(H, W, focal, rays=rays[0], randoms=rnds[0], **okw)
+    rgb_c, _, _, _, ex_c = O.render(H, W, focal, rays=rays[1], randoms=rnds[1], detach_weights=True, **okw)
+    _, disp_i, _, _, ex_i = O.render(H, W, focal, rays=rays[2], randoms=rnds[2], **okw)
+    ref = (O.img2mse(rgb, c["t_clf"]) + O.img2mse(rgb_c, c["t_all"]) + O.img2mse(ex_c["rgb0"], c["t_all"])
+           + O.img2mse(ex["rgb0"], c["t_clf"]) + O.img2mse(disp_i, c["d_inp"]) + O.img2mse(ex_i["disp0"], c["d_inp"]))
+    ref.backward()
+    ref_psnr = -10.0 * float(torch.log10(O.img2mse(rgb, c["t_clf"]).detach()))
+
+    # ---- the direct route (taken by default) ----
+    p0 = [n.flat.detach().clone() for n in (net_c, net_f)]
+    assert tr._spin_direct_ok(args, dict(randoms=curnd))
+    loss, psnr = tr.spin_iteration(*args, randoms=curnd)
+    assert abs(float(loss) - float(ref.detach())) < 2e-4 * abs(float(ref.detach())), (float(loss), float(ref.detach()))
+    assert abs(float(psnr) - ref_psnr) < 1e-3
+    assert tr.global_step == 1
+    g_direct = [n.flat.grad.clone() for n in (net_c, net_f)]
+    for net, p in ((net_c, pc), (net_f, pf)):
+        got = net.named_views(net.flat.grad)
+        for k, v in p.items():
+            a, b = got[k].cpu().double().reshape(-1), v.grad.double().reshape(-1)
+            rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            assert rel < 5e-3, f"{k}: relative L2 error {rel:.2e}"
+    # every map the three renders return: the concatenated render's rows
+    h = tr._last_spin
+    N = c["N"]
+    assert float((h.rgb[:N].cpu() - rgb.detach()).abs().max()) < 2e-4
+    assert float((h.rgb[N:2 * N].cpu() - rgb_c.detach()).abs().max()) < 2e-4
+    assert float(((h.disp[2 * N:].cpu() - disp_i.detach()) / disp_i.detach()).abs().max()) < 2e-3
+
+    # ---- the autograd route on the same parameters and draws ----
+    def restore():
+        for n, p in zip((net_c, net_f), p0):
+            with torch.no_grad():
+                n.flat.copy_(p)
+            n.mark_weights_changed()
+            n.flat.grad = None
+    restore()
+    monkeypatch.setenv("SNR_NO_DIRECT_SPIN", "1")
+    assert not tr._spin_direct_ok(args, dict(randoms=curnd))
+    loss_a, psnr_a = tr.spin_iteration(*args, randoms=curnd)
+    monkeypatch.delenv("SNR_NO_DIRECT_SPIN")
+    assert abs(float(loss_a) - float(loss)) < 2e-6 * abs(float(loss)), (float(loss_a), float(loss))
+    assert abs(float(psnr_a) - float(psnr)) < 1e-4
+    for n, gd in zip((net_c, net_f), g_direct):
+        assert float((n.flat.grad - gd).norm() / gd.norm()) < 2e-5
+
+    # ---- NaN guard: a NaN among the disparity targets drops the geometry term and its gradient, nothing else ----
+    restore()
+    bad = c["d_inp"].clone(); bad[3] = float("nan")
+    args_bad = args[:8] + (cu(bad),)
+    loss_n, _ = tr.spin_iteration(*args_bad, randoms=curnd)
+    ref_ab = float((O.img2mse(rgb, c["t_clf"]) + O.img2mse(rgb_c, c["t_all"]) + O.img2mse(ex_c["rgb0"], c["t_all"])
+                    + O.img2mse(ex["rgb0"], c["t_clf"])).detach())
+    assert np.isfinite(float(loss_n)) and abs(float(loss_n) - ref_ab) < 2e-4 * ref_ab
+    g_n = [n.flat.grad.clone() for n in (net_c, net_f)]
+    assert all(bool(torch.isfinite(g).all()) for g in g_n)
+    restore()
+    monkeypatch.setenv("SNR_NO_DIRECT_SPIN", "1")
+    tr.spin_iteration(*args_bad, randoms=curnd)
+    monkeypatch.delenv("SNR_NO_DIRECT_SPIN")
+    for n, gd in zip((net_c, net_f), g_n):
+        assert float((n.flat.grad - gd).norm() / gd.norm()) < 2e-5
+    # ... and with in-kernel draws the iteration simply runs
+    l2, psnr2 = tr.spin_iteration(*args)
+    assert np.isfinite(float(l2)) and np.isfinite(float(psnr2))
+
+
+def test_direct_spin_iteration_bf16_runs_on_the_merged_backward():
+    """bf16 (the bench's precision): the direct iteration's gradients against the autograd route's, which runs the three
+    renders one after the other; the two differ only by the split-K partition of the bf16 partial sums (documented 6e-3)."""
+    import os
+    c = _spin_setup(precision="bf16", N=64)
+    tr, (net_c, net_f) = c["tr"], c["nets"]
+    H, W, focal = c["hwf"]
+    cu = lambda t: t.cuda()
+    curnd = [{k: cu(v) for k, v in r.items()} for r in c["rnds"]]
+    args = (H, W, focal, cu(c["rays"][0]), cu(c["t_clf"]), cu(c["rays"][1]), cu(c["t_all"]), cu(c["rays"][2]), cu(c["d_inp"]))
+    p0 = [n.flat.detach().clone() for n in (net_c, net_f)]
+    loss, _ = tr.spin_iteration(*args, randoms=curnd)
+    g_direct = [n.flat.grad.clone() for n in (net_c, net_f)]
+    for n, p in zip((net_c, net_f), p0):
+        with torch.no_grad():
+            n.flat.copy_(p)
+        n.mark_weights_changed()
+        n.flat.grad = None
+    os.environ["SNR_NO_DIRECT_SPIN"] = "1"
+    try:
+        loss_a, _ = tr.spin_iteration(*args, randoms=curnd)
+    finally:
+        del os.environ["SNR_NO_DIRECT_SPIN"]
+    assert abs(float(loss_a) - float(loss)) < 1e-5 * abs(float(loss))
+    for n, gd in zip((net_c, net_f), g_direct):
+        assert float((n.flat.grad - gd).norm() / gd.norm()) < 6e-3
+
+
 def test_colmap_depth_render_and_prepare_export_and_lpips_hookup(tmp_path):
     """The rest of the iteration (run_nerf.py:1473-1507, 1523-1561, 1563-1609): the render with the COLMAP `depths=` column
     and its depth loss against the oracle (loss value and gradients), the perceptual term's patch renders with a stand-in
