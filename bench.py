@@ -367,17 +367,28 @@ def main():
         def spin_iter(i):
             (r0, t0_), (r1, t1_), (r2, _) = batches[i % n_batches], batches[(i + 1) % n_batches], batches[(i + 2) % n_batches]
             trainer.spin_iteration(H, W, focal, r0, t0_, r1, t1_, r2, d_inp, batched=True)
-        for i in range(ns.warmup):
-            spin_iter(i)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for i in range(ns.steps):
-            spin_iter(ns.warmup + i)
-        torch.cuda.synchronize()
-        ts = (time.perf_counter() - ts) / ns.steps
+        def time_spin():
+            for i in range(ns.warmup):
+                spin_iter(i)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(ns.steps):
+                spin_iter(ns.warmup + i)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / ns.steps
+        direct = trainer._spin_direct_ok((H, W, focal, batches[0][0], batches[0][1], batches[1][0], batches[1][1], batches[2][0], d_inp), {})
+        ts = time_spin()
+        os.environ["SNR_NO_DIRECT_SPIN"] = "1"     # the same iteration through render() x 3 + torch autograd (round 4's route)
+        try:
+            ts_autograd = time_spin()
+        finally:
+            del os.environ["SNR_NO_DIRECT_SPIN"]
         spin = {"workload": "SPIn-NeRF iteration = 3 renders of N_rand rays (clf, complete with detach_weights, inpainted "
                             "disparity) + losses + backward + Adam, LPIPS / COLMAP terms off", "iterations_per_s": 1.0 / ts,
-                "ms_per_iteration": ts * 1e3, "rays_per_s": 3 * ns.n_rand / ts}
+                "ms_per_iteration": ts * 1e3, "rays_per_s": 3 * ns.n_rand / ts,
+                "route": "library calls: step_prepare, render_rays_fused_forward_terms (one render of the 3 x N_rand rays, three loss "
+                         "terms), render_rays_fused_backward (one launch sequence), adam_pack_multi" if direct else "render() x 3 + autograd",
+                "autograd_route": {"ms_per_iteration": ts_autograd * 1e3, "rays_per_s": 3 * ns.n_rand / ts_autograd}}
 
     if world > 1:   # leave together: rank 0 may still have been rendering its frame
         import torch.distributed as dist

@@ -20,6 +20,10 @@ BASELINE.json asks for +-0.1 dB on the statue scene (not in the container): the 
 EXTENSION (the one decision taken after seeing data, recorded here before its run): the first 16 pairs gave a standard error
 of 0.116 dB on the primary statistic, above the 0.1 dB the plan asked for; SEED0=16 runs 16 more seeds (16..31) with nothing
 else changed, and the pooled 32-pair statistic is reported BESIDE the 16-pair one (profiles/r04_psnr_heldout.txt).
+
+ROUND 5 BLOCK (decided by the round-4 review, recorded here before its run): SEED0=32 SEEDS=32 — seeds 32..63, same script,
+same statistic, no exclusions; reported per 16-pair block and pooled over all 64 pairs (profiles/r05_psnr_heldout.txt).  If the
+pooled held-out difference is below -0.1 dB at 2 standard errors, README and DESIGN section 2 say so.
 """
 import argparse
 import contextlib
