@@ -130,7 +130,7 @@ def launch_ranks(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of the run; default: WORLD_SIZE of the launcher, else 1")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--no-frame", action="store_true")
     ap.add_argument("--no-hashgrid", action="store_true", help="skip the extra measurements (BASELINE config 5 hash-grid networks, config 3 iteration)")
     ns = ap.parse_args()
+    if ns.gpus is None:     # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's world is the run's size
+        ns.gpus = int(os.environ.get("WORLD_SIZE", "1"))
 
     if ns.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves — fresh child processes created
@@ -171,7 +173,9 @@ def main():
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if ns.gpus != world:
-        # (a scaling run must never silently measure another number of GPUs than it was asked for)
+        # (a scaling run must never silently measure another number of GPUs than it was EXPLICITLY asked for)
+        if world > 1:
+            dist.destroy_process_group()
         raise SystemExit(f"bench.py: --gpus {ns.gpus} but WORLD_SIZE={world}")
 
     import spin_nerf_amd as S

@@ -56,6 +56,7 @@ class LossTerms(_c.Structure):      # snr_loss_terms
     _fields_ = [("n_terms", _i), ("term", LossTerm * 4), ("guard_term", _i)]
 
 
+ERR_UNSUPPORTED = -3                # SNR_ERR_UNSUPPORTED
 LOSS_RGB, LOSS_RGB_DETACHED, LOSS_DISP = 0, 1, 2
 RENDER_Z_COARSE_READY, RENDER_LOSS4 = 1, 2
 

@@ -781,6 +781,7 @@ struct WgNet {            // one network's part of the launch
 };
 constexpr int kSyncWords = 256;      // progress words reserved per network (>= its pair slots: n_slots is clamped to 128)
 constexpr int kMaxPairSlots = 128;
+constexpr int kMaxPlainWgs = 256;   // plain workgroups of the launch, at most
 struct WgAllPlan {
   PairArgs pa;            // kernel arguments (pointers still to be filled in: fill_wgall_pointers)
   int grid;               // workgroups of the launch
@@ -797,15 +798,17 @@ inline void wgall_shape(int* n_slots, int* n_plain) {
   if (slots < kMaxPairs) slots = kMaxPairs;
   int plain = tunables().plain_wgs > 0 ? tunables().plain_wgs : cus - 2 * slots;
   if (plain < kMaxPlain) plain = kMaxPlain;
-  if (plain > 256) plain = 256;
+  if (plain > kMaxPlainWgs) plain = kMaxPlainWgs;
   *n_slots = slots; *n_plain = plain;
 }
 
 // upper bound of a network's partial-sum floats in ANY launch it may take part in (alone or merged with another network):
 // every split of every job is at most the largest plane of its kind
+// The bound holds for every launch shape wgall_shape can return — its CLAMPS, not the current tunables or the current
+// device's CU count: a workspace sized before snr_tunables_reload() raised SNR_PAIR_SLOTS / SNR_PLAIN_WGS, or with another
+// device current, stays large enough (120 MB per network instead of ~70, untouched unless used).
 inline int64_t wgall_part_bound() {
-  int n_slots, n_plain;
-  wgall_shape(&n_slots, &n_plain);
+  const int n_slots = kMaxPairSlots, n_plain = kMaxPlainWgs;
   const int64_t pair_split = 2 * (256 * 256 + 256);        // kind A + kind B planes of a hidden layer pair, with their bias rows
   const int64_t plain_split = 160 * 288 + 160;             // [d z9 | d out] x [h7 | dir]: 5 x 9 tiles
   return (int64_t)(n_slots + kMaxPairs) * pair_split + (int64_t)(n_plain + kMaxPlain) * plain_split + kSyncWords;

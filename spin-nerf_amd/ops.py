@@ -586,7 +586,11 @@ def adam_pack_step_(nets, grads, exp_avgs, exp_avg_sqs, lr, step, beta1=0.9, bet
         packed = net.packed_weights()      # (packs once if the blob is missing or stale: its padding must exist)
         items[i] = _lib.AdamPackItem(ctypes.pointer(net.cfg), ptr(net.flat.data), ptr(g), ptr(m), ptr(v), ptr(packed))
         keep.append((packed, g))
-    check(lib.snr_adam_pack_multi(items, len(nets), float(lr), float(beta1), float(beta2), float(eps), int(step),
-                                  float(grad_scale), None, stream()), "snr_adam_pack_multi")
+    st = lib.snr_adam_pack_multi(items, len(nets), float(lr), float(beta1), float(beta2), float(eps), int(step),
+                                 float(grad_scale), None, stream())
+    if st == _lib.ERR_UNSUPPORTED:
+        return False      # a shape the fused kernel does not cover: nothing was launched (the caller groups equal configurations only)
+    check(st, "snr_adam_pack_multi")
     for net in nets:
         net.note_packed_in_place()
+    return True

@@ -631,14 +631,21 @@ class RenderTrainer:
         from .nerf import NeRF
         live = [(n, m, v) for n, m, v in zip(self.nets, self.m, self.v) if n.flat.grad is not None]   # torch.optim.Adam skips parameters without a gradient
         fused = [t for t in live if type(t[0]) is NeRF and t[0].flat.is_cuda and os.environ.get("SNR_NO_ADAM_PACK") != "1"]
+        done = []
         if fused:
-            # Adam + the re-pack of the weights of both MLPs: ONE launch (csrc/adam_pack.hip) instead of two Adam and two pack launches
-            for k in range(0, len(fused), 2):
-                grp = fused[k:k + 2]
-                ops.adam_pack_step_([t[0] for t in grp], [t[0].flat.grad for t in grp], [t[1] for t in grp], [t[2] for t in grp],
-                                    lr, self.opt_step, grad_scale=1.0 / self.world_size)
+            # Adam + the re-pack of the weights of both MLPs: ONE launch (csrc/adam_pack.hip) instead of two Adam and two pack launches.
+            # Two networks share a call only when their configurations are equal (then the call is one launch, and
+            # SNR_ERR_UNSUPPORTED — a shape the fused kernel does not cover — means nothing ran: the generic route below takes over)
+            k = 0
+            while k < len(fused):
+                pair = k + 1 < len(fused) and fused[k][0].cfg.key() == fused[k + 1][0].cfg.key()
+                grp = fused[k:k + (2 if pair else 1)]
+                k += len(grp)
+                if ops.adam_pack_step_([t[0] for t in grp], [t[0].flat.grad for t in grp], [t[1] for t in grp], [t[2] for t in grp],
+                                       lr, self.opt_step, grad_scale=1.0 / self.world_size):
+                    done.extend(t[0] for t in grp)
         for n, m, v in live:
-            if any(n is t[0] for t in fused):
+            if any(n is d for d in done):
                 continue
             ops.adam_step_(n.flat.data, n.flat.grad, m, v, lr, self.opt_step, grad_scale=1.0 / self.world_size)
             n.mark_weights_changed()   # written through a raw pointer: re-pack before the next forward

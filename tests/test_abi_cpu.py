@@ -246,11 +246,21 @@ def test_process_wide_settings_are_read_once_and_thread_safe(S, monkeypatch):
     [t.join() for t in ts]
     base = out[0][0]
     assert base > 0 and all(v == base for o in out for v in o)
-    monkeypatch.setenv("SNR_PAIR_SLOTS", "64")          # half the pair slots: a smaller partial-sum buffer ...
-    assert lib.snr_mlp_bwd_ws_bytes(cfg, n) == base      # ... but not before the switches are read again
+    # the workspace bound covers every launch shape the switches can select (round 5, ADVICE r04: a size query must stay
+    # valid across snr_tunables_reload and across devices): SNR_PAIR_SLOTS / SNR_PLAIN_WGS do not move it ...
+    monkeypatch.setenv("SNR_PAIR_SLOTS", "64")
+    monkeypatch.setenv("SNR_PLAIN_WGS", "200")
     lib.snr_tunables_reload()
-    assert 0 < lib.snr_mlp_bwd_ws_bytes(cfg, n) < base
+    assert lib.snr_mlp_bwd_ws_bytes(cfg, n) == base
     monkeypatch.delenv("SNR_PAIR_SLOTS")
+    monkeypatch.delenv("SNR_PLAIN_WGS")
+    # ... while a switch that changes what the backward stores does, but not before the switches are read again
+    monkeypatch.setenv("SNR_RECOMPUTE", "0")            # every layer's d z saved, plain split-K pass
+    assert lib.snr_mlp_bwd_ws_bytes(cfg, n) == base
+    lib.snr_tunables_reload()
+    other = lib.snr_mlp_bwd_ws_bytes(cfg, n)
+    assert other > 0 and other != base
+    monkeypatch.delenv("SNR_RECOMPUTE")
     lib.snr_tunables_reload()
     assert lib.snr_mlp_bwd_ws_bytes(cfg, n) == base
     # new entry points: argument checks before any device access
@@ -261,5 +271,7 @@ def test_process_wide_settings_are_read_once_and_thread_safe(S, monkeypatch):
     ap = (S._lib.AdamPackItem * 1)()
     assert lib.snr_adam_pack_multi(ap, 1, 5e-4, 0.9, 0.999, 1e-8, 0, 1.0, None, None) == -2   # step is 1-based
     rc = S._lib.RenderConfig(64, 128, 0, 0, 1, 1.0, 0)
+    assert lib.snr_render_rays_fused_forward_terms(ctypes.byref(rc), None, None, None, 11, 8, None, None, None, None, 0, 0, None, None,
+                                                   None, None, None, None, None, None, None, None, None, None, None) == -1
     assert lib.snr_render_step_prepare(ctypes.byref(rc), None, None, 8, 4, 4, 1.0, 0, 0.0, 1.0, 1, None, 11, None, 0, 0, None,
                                        None, None, None) == -1
