@@ -35,6 +35,9 @@ class RenderTrainer:
         self.nets = [n for n in (self.kw.get('network_fn'), self.kw.get('network_fine')) if n is not None]
         self.lrate, self.lrate_decay = lrate, lrate_decay
         self.world_size, self.pg = world_size, process_group
+        # collectives run when there is more than one rank — or when SNR_FORCE_COLLECTIVES=1 asks a ONE-rank group to exercise
+        # the collective code path (backend construction, async all-reduce on the gradient buffer, wait): tests/test_gpu_nccl_one_rank.py
+        self._dist = world_size > 1 or os.environ.get("SNR_FORCE_COLLECTIVES") == "1"
         self.global_step = 0          # completed optimisation steps (the reference's global_step after its increment)
         self.opt_step = 0             # Adam's own step count (bias correction)
         self._lr = lrate              # rate the NEXT step uses (run_nerf.py:1616-1622 sets it after each step)
@@ -52,12 +55,12 @@ class RenderTrainer:
         # The all-reduce of a net's gradient starts the moment autograd has finished that net (the fine net's
         # runs under the coarse net's backward); apply_gradients() only waits.
         self._works = {}
-        if world_size > 1:
+        if self._dist:
             for i, n in enumerate(self.nets):
                 n.flat.register_post_accumulate_grad_hook(lambda p, i=i: self._start_all_reduce(i, p))
 
     def _rank(self):
-        if self.world_size > 1:
+        if self._dist:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
                 return dist.get_rank(self.pg)
@@ -87,7 +90,7 @@ class RenderTrainer:
 
     def broadcast_parameters(self, src=0):
         """identical replicas at start (rank `src`'s init wins)"""
-        if self.world_size > 1:
+        if self._dist:
             import torch.distributed as dist
             for n in self.nets:
                 dist.broadcast(n.flat.data, src=src, group=self.pg)
@@ -107,7 +110,7 @@ class RenderTrainer:
         (or taken from ``randoms=``), and each network's compositing forward, loss term and compositing backward are
         one kernel (snr_composite_train).  Anything else goes through render() + autograd."""
         if self._direct_ok(batch_rays, chunk, extra):
-            if (self._graph_on and self.world_size == 1 and not extra.get("randoms")
+            if (self._graph_on and not self._dist and not extra.get("randoms")
                     and os.environ.get("SNR_NO_FUSED_STEP") != "1"):
                 return self._step_graph(H, W, focal, batch_rays, target_s)
             return self._step_direct(H, W, focal, batch_rays, target_s, extra.get("randoms"))
@@ -175,7 +178,7 @@ class RenderTrainer:
                 ops.fused_backward(h, g_c, g_f)
                 net_f.flat.grad = g_f
                 net_c.flat.grad = g_c
-                if self.world_size > 1 and os.environ.get("SNR_SPLIT_ALLREDUCE") != "1":
+                if self._dist and os.environ.get("SNR_SPLIT_ALLREDUCE") != "1":
                     import torch.distributed as dist
                     work = dist.all_reduce(g_both, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                     self._works[self.nets.index(net_c)] = self._works[self.nets.index(net_f)] = work
@@ -227,7 +230,7 @@ class RenderTrainer:
                 g_f = ops.mlp_train_backward(net_f, sv_f, out_f[5])
                 if net_f is not net_c:
                     net_f.flat.grad = g_f
-                    if self.world_size > 1:     # like the autograd hook: the fine net's all-reduce runs under the coarse backward
+                    if self._dist:     # like the autograd hook: the fine net's all-reduce runs under the coarse backward
                         self._start_all_reduce(self.nets.index(net_f), net_f.flat)
                 g_c = ops.mlp_train_backward(net_c, sv_c, out_c[5])
             net_c.flat.grad = g_c + g_f if net_f is net_c else g_c
@@ -495,7 +498,7 @@ class RenderTrainer:
             ops.fused_backward(h, g_c, g_f)
             net_f.flat.grad = g_f
             net_c.flat.grad = g_c
-            if self.world_size > 1 and os.environ.get("SNR_SPLIT_ALLREDUCE") != "1":
+            if self._dist and os.environ.get("SNR_SPLIT_ALLREDUCE") != "1":
                 import torch.distributed as dist
                 work = dist.all_reduce(g_both, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 self._works[self.nets.index(net_c)] = self._works[self.nets.index(net_f)] = work
@@ -598,13 +601,13 @@ class RenderTrainer:
     def comm_ms_per_step(self):
         """Stream time the optimizer step spent waiting for the gradient all-reduce (events around the waits), per step
         since comm_reset(); None on one GPU."""
-        if self.world_size <= 1 or not getattr(self, "_comm_steps", 0):
+        if not self._dist or not getattr(self, "_comm_steps", 0):
             return None
         torch.cuda.synchronize()
         return sum(a.elapsed_time(b) for a, b in self._comm_events) / self._comm_steps
 
     def apply_gradients(self):
-        if self.world_size > 1:
+        if self._dist:
             import torch.distributed as dist
             idle = []                            # networks without a gradient: every rank agrees on which (same code path)
             for i, n in enumerate(self.nets):   # anything the hooks did not see (gradients set by hand)

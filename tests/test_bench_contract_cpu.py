@@ -42,6 +42,26 @@ def test_committed_bench_line_has_the_contract_fields():
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1
 
 
+def test_every_kernels_key_of_the_bench_line_is_a_kernel_of_the_rocprofv3_trace():
+    """bench.py's `kernels` keys are the names of the kernels that run (csrc/prof.cpp names them after the
+    __global__ functions): every key + "_kernel" must be the prefix of a kernel name in the SAME round's `--kernel-trace --stats`
+    CSV, every launch is counted as a launch (no "+ 1"), and the step's launches add up to what the trace shows per step.
+    (Rounds before 5 used coarser labels: composite_fwd, make_rays, adam.)"""
+    import csv
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))
+    tag = re.match(r"(r\d+)_", os.path.basename(files[-1])).group(1)
+    stats = os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv")
+    if int(tag[1:]) < 5 or not os.path.exists(stats):
+        import pytest
+        pytest.skip("no round >= 5 profile committed yet")
+    d = _latest_line()
+    names = [r["Name"] for r in csv.DictReader(open(stats))]
+    for k in d["kernels"]:
+        assert any((k + "_kernel") in n for n in names), (k, "not a kernel of", stats)
+    assert abs(d["launches_per_step"] - sum(v["launches_per_step"] for v in d["kernels"].values())) < 1e-9
+
+
 def test_bench_flop_model_matches_the_network_shapes():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
