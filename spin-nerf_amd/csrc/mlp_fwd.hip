@@ -341,8 +341,14 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
             if constexpr (TRAIN) { if constexpr (!kSplit) act_store(AL.k_h9(), IH9{}, h9, IH{}, 0, I1{}); mask_store(AL.k_mask9(), pmask); }
           });
 #pragma unroll
-      for (int jt = 0; jt < NJ; ++jt)
-        if (valid[jt] && g == 0) *(f32x4*)(a.raw + 4 * m[jt]) = f32x4{acc_c[jt][0], acc_c[jt][1], acc_c[jt][2], alpha[jt]};
+      for (int jt = 0; jt < NJ; ++jt) {
+        // the sample index is re-derived here (an opaque copy of the lane's sample number): kept from the top of the pass it
+        // was a 64-bit value live across all eleven stages, and since round 5 (stores behind the epilogues) it went to scratch
+        int sj2 = sj;
+        asm volatile("" : "+v"(sj2));
+        const int64_t mm = (tile0 + jt) * 32 + sj2;
+        if (mm < a.n_samples && g == 0) *(f32x4*)(a.raw + 4 * mm) = f32x4{acc_c[jt][0], acc_c[jt][1], acc_c[jt][2], alpha[jt]};
+      }
     } else {
       f32x16 acc_o[NJ];
       pipe.template run_tiles<0, KS_H, 1, NJ, KS_H, KS_H>(
