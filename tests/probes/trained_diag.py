@@ -28,6 +28,9 @@ for name in (sys.argv[1:] or TRAINED_CASES):
       with torch.no_grad():
           r2, d2, a2, w2, dp2, _ = S.raw2outputs(raw, z, rays[:, 3:6], white_bkgd=bool(g["white"]), noise=rnd["noise_f"].cuda() if rnd["noise_f"] is not None else None, rays=rays)
       print(prec, "teacher-forced rgb", d(r2, g["rgb"].reshape(n, 3)), "acc", d(a2, g["acc"].reshape(n)), "weights", d(w2, g["x_weights"].reshape(n, -1)),
+            "opacity at the reference's half-way sample", (lambda cr, ch: float(np.abs(np.take_along_axis(ch, (cr >= 0.5).argmax(-1)[:, None], 1) - np.take_along_axis(cr, (cr >= 0.5).argmax(-1)[:, None], 1))[cr[:, -1] >= 0.5].max()))(np.cumsum(g["x_weights"].reshape(n, -1), -1), np.cumsum(R.npy(w2), -1)),
+            "acc before the last sample", float(np.abs(R.npy(w2)[:, :-1].sum(-1) - g["x_weights"].reshape(n, -1)[:, :-1].sum(-1)).max()),
+            "(reference range", float(g["x_weights"].reshape(n, -1)[:, :-1].sum(-1).min()), float(g["x_weights"].reshape(n, -1)[:, :-1].sum(-1).max()), ")",
             "depth", d(dp2, g["depth"].reshape(n)), "disp rel", float(np.nanmax(np.abs(R.npy(d2) - g["disp"].reshape(n)) / np.abs(g["disp"].reshape(n)))), "NaN pattern equal", bool((np.isnan(R.npy(d2)) == np.isnan(g["disp"].reshape(n))).all()))
       # gradients
       net_c, net_f, kw = R.build(S, g, prec)

@@ -43,7 +43,8 @@ for force in ("1", "0"):
         res[(force, split)] = (float(loss), float(l2), [x.flat.detach().clone() for x in nets])
 base = res[("0", "0")]
 for key, (l, l2, params) in res.items():
-    assert l == base[0] and l2 == base[1], (key, l, base[0], l2, base[1])
+    # (the loss VALUE is a sum of per-workgroup atomics: its last bits depend on their order; the parameters do not)
+    assert abs(l - base[0]) < 1e-6 * abs(base[0]) and abs(l2 - base[1]) < 1e-6 * abs(base[1]), (key, l, base[0], l2, base[1])
     for a, b in zip(params, base[2]):
         assert torch.equal(a, b), key
 dist.barrier()

@@ -420,21 +420,25 @@ def test_embedder_call_matches_reference_embedding(S):
 
 
 # ---- the benched dtype on networks the REFERENCE trained (tests/golden/make_golden_trained.py) ----
-# 200 Adam steps of the reference's own modules on the analytic sphere, seeded and regenerable (`--check`).  Gates = 2x what
-# tests/probes/trained_diag.py measures on MI355X with the regenerated fixtures:
-#   white background + density noise (raw up to 41 / 52; every ray opaque, acc == 1): coarse rgb0 3.4e-3, free-running rgb
-#     1.3e-3, raw 0.11 = 0.27 % of its range, weights 8.9e-4, depth 1.7e-4, relative disparity 7.7e-5, loss 6.6e-4 relative,
-#     parameter gradients 3.2e-2 (coarse) / 8.6e-3 (fine) relative L2 — SURVEY.md §7(b) expected rgb ~3e-3, raw ~1e-2;
-#   black background, no noise (acc from 0.006 to 0.997: 28 of 48 rays below 0.99, 10 below 0.5 — the semi-transparent and
-#     empty rays the white scene never produces): coarse rgb0 1.2e-3, acc0 1.6e-3, free-running rgb 5.8e-3, acc 6.4e-3, raw
-#     0.15 = 0.34 %, weights 2.8e-3, depth 1.1e-2, relative disparity 1.1e-3, loss 7.7e-3, gradients 2.8e-2 / 0.11 (a ray that
-#     is not opaque passes every bf16 rounding of its densities on to the transmittance of all samples behind).
+# 200 Adam steps of the reference's own modules on the analytic sphere, seeded and regenerable (`--check`).  Gates = 1.5x (round
+# 5; before: 2x) what tests/probes/trained_diag.py measures on MI355X — the bf16 arithmetic is deterministic, so the measured
+# value is what every box computes:
+#   white background + density noise (raw up to 41 / 52; every ray opaque long before its last sample): coarse rgb0 3.41e-3,
+#     free-running rgb 1.29e-3, raw 0.111 = 0.21 % of its range, weights 8.9e-4, opacity at the reference's half-way sample
+#     5.7e-4, depth 1.66e-4, relative disparity 7.7e-5, loss 6.6e-4 relative, parameter gradients 3.16e-2 (coarse) / 8.6e-3
+#     (fine) relative L2;  acc itself is 1 to 2e-7 in any arithmetic here (no gate on it: it could not fail — the half-way
+#     opacity is the quantity that can);
+#   black background, no noise (acc from 0 to 0.9996: 28 of 48 rays below 0.99, 10 below 0.5): coarse rgb0 1.22e-3, acc0
+#     1.58e-3, free-running rgb 5.84e-3, acc 6.43e-3, raw 0.149 = 0.34 %, weights 2.79e-3, half-way opacity 1.56e-3, depth
+#     1.06e-2, relative disparity 1.11e-3, loss 7.7e-3, gradients 2.8e-2 / 0.109.  What the 0.109 is made of:
+#     profiles/r05_bf16_grad_decomp.txt — the forward's roundings (encodings 0.069, activations 0.070 in quadrature); the
+#     backward's own (bf16 d z, bf16 split-K partial sums) 0.001 each.
 # (fp32 mode on the same fixtures: rgb 2e-6, raw 2e-5, gradients 1.5e-5 / 7e-3 — held by the generic tests above.)
 BF16_TRAINED_GATES = {
-    "render_trained_fine_vd": dict(rgb=3e-3, rgb0=7e-3, acc=1e-5, raw_frac=6e-3, weights=3e-3, depth=6e-4, disp_rtol=3e-4,
-                                   loss_rtol=2.5e-3, grad_coarse=6.5e-2, grad_fine=7e-2),
-    "render_trained_black_vd": dict(rgb=1.2e-2, rgb0=2.5e-3, acc=1.3e-2, raw_frac=7e-3, weights=6e-3, depth=2.2e-2, disp_rtol=2.5e-3,
-                                    loss_rtol=1.6e-2, grad_coarse=6e-2, grad_fine=0.22),
+    "render_trained_fine_vd": dict(rgb=2.0e-3, rgb0=5.2e-3, acc=None, half=8.6e-4, raw_frac=3.3e-3, weights=1.35e-3, depth=2.5e-4,
+                                   disp_rtol=1.2e-4, loss_rtol=1.0e-3, grad_coarse=4.8e-2, grad_fine=1.3e-2),
+    "render_trained_black_vd": dict(rgb=8.8e-3, rgb0=1.85e-3, acc=9.7e-3, half=2.4e-3, raw_frac=5.1e-3, weights=4.2e-3, depth=1.6e-2,
+                                    disp_rtol=1.7e-3, loss_rtol=1.16e-2, grad_coarse=4.3e-2, grad_fine=0.165),
 }
 
 
@@ -450,9 +454,10 @@ def test_render_bf16_on_reference_trained_networks(S):
         # the whole free-running pipeline: trained networks put their probability mass in few bins, resampling is
         # well-conditioned there and the maps can be held directly
         close(ex["rgb0"], g["x_rgb0"], atol=G["rgb0"], rtol=0, msg="rgb0")
-        close(ex["acc0"], g["x_acc0"], atol=G["acc"], rtol=0, msg="acc0")
         close(rgb, g["rgb"], atol=G["rgb"], rtol=0, msg="rgb")
-        close(acc, g["acc"], atol=G["acc"], rtol=0, msg="acc")
+        if G["acc"] is not None:
+            close(ex["acc0"], g["x_acc0"], atol=G["acc"], rtol=0, msg="acc0")
+            close(acc, g["acc"], atol=G["acc"], rtol=0, msg="acc")
         # fine stage on the reference's z_vals: raw, then the maps composited from the kernel's own raw
         rays = pack_rays(S, g)
         z = T(g["x_z_vals"]).reshape(n, -1).cuda()
@@ -464,7 +469,16 @@ def test_render_bf16_on_reference_trained_networks(S):
         with torch.no_grad():
             r2, d2, a2, w2, dp2, _ = S.raw2outputs(raw, z, rays[:, 3:6], white_bkgd=bool(g["white"]),
                                                    noise=rnd["noise_f"].cuda() if rnd["noise_f"] is not None else None, rays=rays)
-        close(a2, g["acc"].reshape(n), atol=G["acc"], rtol=0, msg="acc (teacher-forced)")
+        if G["acc"] is not None:
+            close(a2, g["acc"].reshape(n), atol=G["acc"], rtol=0, msg="acc (teacher-forced)")
+        # accumulated opacity where the reference's reaches one half: moves with every density in front of it, on every
+        # fixture (on the white one acc itself is 1 whatever the network says)
+        cr, ch = np.cumsum(g["x_weights"].reshape(n, -1), -1), np.cumsum(npy(w2), -1)
+        k = (cr >= 0.5).argmax(-1)[:, None]
+        hit = cr[:, -1] >= 0.5
+        assert hit.sum() >= 10
+        err = np.abs(np.take_along_axis(ch, k, 1) - np.take_along_axis(cr, k, 1))[hit].max()
+        assert err < G["half"], f"opacity at the reference's half-way sample: {err:.3e}"
         close(r2, g["rgb"].reshape(n, 3), atol=G["rgb"], rtol=0, msg="rgb (teacher-forced)")
         close(w2, g["x_weights"].reshape(n, -1), atol=G["weights"], rtol=0, msg="weights")
         close(dp2, g["depth"].reshape(n), atol=G["depth"], rtol=0, msg="depth")

@@ -123,6 +123,9 @@ def _two_trainers(precision="fp32", Nf=128):
     return out, (H, W, focal), rays, target, rnd
 
 
+MERGED_GATE_W, MERGED_GATE_B = 2.7e-3, 1e-5   # measured on MI355X: 1.77e-3 (pts_linears.0.weight), 1e-7 (bias partial sums stay fp32)
+
+
 @pytest.mark.parametrize("precision,Nf", [("fp32", 128), ("bf16", 128), ("fp32", 0)])
 def test_autograd_free_step_equals_the_autograd_step(monkeypatch, precision, Nf):
     """RenderTrainer.step issues the launches of the plain configuration directly (compositing forward + loss + backward in
@@ -157,6 +160,22 @@ def test_autograd_free_step_equals_the_autograd_step(monkeypatch, precision, Nf)
             (c, d), hwf, rays, target, rnd2 = _two_trainers(precision, Nf)
             rnd2 = {k: v for k, v in rnd2.items() if v is not None}
             c[0].step(*hwf, rays, target, randoms=rnd2)
+            # the MERGED direct step (trainer a above, the default route) against the unmerged one, PER PARAMETER TENSOR (ADVICE
+            # r04: the whole-network 6e-3 was all that held the default route).  Same parameters, same draws; the two differ only
+            # in which 32-sample tiles share a bf16-rounded split-K partial sum — an unbiased perturbation of about
+            # 2^-9 / sqrt(splits) of a tensor's norm.  Gates = 1.5x the worst values measured on MI355X (printed below).
+            worst = {"weight": (0.0, ""), "bias": (0.0, "")}
+            for nm, nu in zip(a[1], c[1]):
+                vm, vu = nm.named_views(nm.flat.grad), nu.named_views(nu.flat.grad)
+                for k in vu:
+                    if float(vu[k].abs().max()) == 0.0:
+                        continue
+                    rel = float((vm[k] - vu[k]).norm() / vu[k].norm())
+                    kind = "weight" if k.endswith("weight") else "bias"
+                    if rel > worst[kind][0]:
+                        worst[kind] = (rel, k)
+            print("merged vs unmerged direct step, worst per-tensor relative L2:", worst)
+            assert worst["weight"][0] < MERGED_GATE_W and worst["bias"][0] < MERGED_GATE_B, worst
             monkeypatch.setenv("SNR_NO_DIRECT_STEP", "1")
             d[0].step(*hwf, rays, target, randoms=rnd2)
             for nc_, nd_ in zip(c[1], d[1]):
