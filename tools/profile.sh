@@ -4,7 +4,7 @@
 # Pass 1: kernel trace + stats of the default bench command.  Passes 2..4: PMC counters, each in its
 # own run with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
