@@ -300,7 +300,14 @@ template <int P, int WAVES_> struct Pipe {
         }
         if constexpr (f == FB && nt + 1 < NT) load_bias(std::integral_constant<int, nt + 1>{});
         if constexpr (i + G < NF) load(std::integral_constant<int, i + G>{});
-        if (NJ > 1 || (f & 1)) issue_one();   // one DMA piece per ~64 cycles of MFMA
+#ifndef SNR_DMA_SPREAD
+#define SNR_DMA_SPREAD 0   // A/B (round 5): 1 = this wave's PIECES pieces of a block evenly over the block's fragments (one per
+#endif                     // BF / PIECES MFMAs) instead of one behind every other MFMA right after the block entry
+        if constexpr (SNR_DMA_SPREAD && NJ == 1) {
+          if constexpr (i % (BF / PIECES) == BF / PIECES - 1) issue_one();
+        } else {
+          if (NJ > 1 || (f & 1)) issue_one();   // one DMA piece per ~64 cycles of MFMA
+        }
       });
       if constexpr (TWO) acc[0] = acc[0] + acc2;
       if constexpr (OVERLAP) {
