@@ -11,8 +11,12 @@
 //     waves 8..11  HELPERS  loaders: every LDS-DMA piece of the weight stream (global_load_lds_dwordx4, L2 -> LDS ring);
 //                           storers (training forward, dgrad): copy staged output tiles LDS -> HBM.
 //
-// The shipped kernels spend +25 % (weight DMA) and +27 % (saved-tensor stores) of their time with the ISSUING wave stuck at a
-// vector-memory instruction and its MFMA chain stopped (profiles/r05_chain_theory_raw.txt); a helper stuck there stops nobody.
+// HYPOTHESIS the structure was built to test: the shipped kernels' +13 ... +32 % (weight DMA) and +20 ... +48 % (saved-tensor
+// stores) are time the ISSUING wave spends stuck at a vector-memory instruction with its MFMA chain stopped; a helper stuck
+// there stops nobody.  OUTCOME (profiles/r05_chain_ab.txt): refuted.  Results are bit-identical, the kernels are 7-11 % slower:
+// a DMA piece costs the compute waves the same whether a helper issues it or they do — it is LDS traffic every fragment read
+// shares —, and the 168-register budget, the spill traffic and the progress words cost a further 8 %.  The code stays behind
+// SNR_CHAIN2=1 (default 0) as the experiment's record and A/B switch; tests/test_gpu_chain2.py holds it bit-identical.
 //
 // Registers: a tile's input (64) and output (64) do not fit 168 next to accumulator, bias and fragment window, so the output
 // of a layer is split: output tiles 0..NREG-1 stay in registers, tiles NREG..7 go to a lane-private LDS spill slot (2 x
@@ -24,9 +28,12 @@
 // multiple of 4 blocks, so the slot of every fragment read is an instruction immediate).  No workgroup barrier in the loop
 // (first version: one raw s_barrier per block, 80 rendezvous of 12 waves per pass = 23 % of the compute waves' time parked,
 // profiles/r05_chain_ab.txt): progress is published through LDS words,
-//   landed     += 1 by every loader once its pieces of the next block have landed (counted vmcnt; blocks land in order)
+//   landed[p]  += 1 by every loader of group p once its pieces of a block of parity p have landed (two loader groups, one per
+//                 block parity: two blocks in flight; a loader waits vmcnt(0) — its only vector-memory operations — and
+//                 publishes at once: nothing a compute wave waits for depends on a LATER block)
 //   done[w]     = blocks compute wave w has completely read (an LDS write behind its last read of the block: LDS operations
 //                 of one wave execute in order)
+//   staged[w] / stored[w]   chunks (output tiles) wave w has put into its spill area for the storers / a storer has read back
 // a compute wave looks at `landed` only when its cached copy does not already cover the block it is about to read, a loader
 // refills the slot of block c-4 when every done[w] >= c-3.  Compute waves never wait for each other; they may drift apart by
 // up to three blocks.
@@ -72,7 +79,7 @@ struct FwdMap {
   static constexpr int B9 = B8 + N8, N9 = 6;                         // views: 4 x 18 = 72 fragments, padded to 96
   static constexpr int B10 = B9 + N9, N10 = 2;                       // rgb: 8 fragments, padded to 32
   static constexpr int kBlocks = B10 + N10;                          // 78
-  static constexpr int kVirtual = (kSlots - kBlocks % kSlots) % kSlots;   // barrier-only blocks that close a pass: 2
+  static constexpr int kVirtual = (kSlots - kBlocks % kSlots) % kSlots;   // padding blocks that close a pass (nobody reads them): 2
   static constexpr int kPassBlocks = kBlocks + kVirtual;             // 80
 };
 static_assert(kBlockFrags == 32 && FwdMap::kBlocks == 78 && FwdMap::kPassBlocks % kSlots == 0, "chain2 assumes the 32-fragment stage padding of mlp_pack.h");
