@@ -220,6 +220,36 @@ def test_direct_spin_iteration_matches_oracle_and_the_autograd_route(monkeypatch
     assert np.isfinite(float(l2)) and np.isfinite(float(psnr2))
 
 
+@pytest.mark.parametrize("N", [1, 37, 130])
+def test_direct_spin_iteration_with_term_boundaries_inside_workgroups(N):
+    """The loss terms' ray ranges need not be multiples of the compositing kernels' 4 rays per workgroup: with N rays per
+    render the boundaries at N and 2 N fall inside a workgroup (its rays then add to different terms' slots).  Direct route
+    against the autograd route, fp32, injected draws."""
+    import os
+    c = _spin_setup(N=N)
+    tr, (net_c, net_f) = c["tr"], c["nets"]
+    H, W, focal = c["hwf"]
+    cu = lambda t: t.cuda()
+    curnd = [{k: cu(v) for k, v in r.items()} for r in c["rnds"]]
+    args = (H, W, focal, cu(c["rays"][0]), cu(c["t_clf"]), cu(c["rays"][1]), cu(c["t_all"]), cu(c["rays"][2]), cu(c["d_inp"]))
+    p0 = [n.flat.detach().clone() for n in (net_c, net_f)]
+    loss, psnr = tr.spin_iteration(*args, randoms=curnd)
+    g_direct = [n.flat.grad.clone() for n in (net_c, net_f)]
+    for n, p in zip((net_c, net_f), p0):
+        with torch.no_grad():
+            n.flat.copy_(p)
+        n.mark_weights_changed()
+        n.flat.grad = None
+    os.environ["SNR_NO_DIRECT_SPIN"] = "1"
+    try:
+        loss_a, psnr_a = tr.spin_iteration(*args, randoms=curnd)
+    finally:
+        del os.environ["SNR_NO_DIRECT_SPIN"]
+    assert abs(float(loss_a) - float(loss)) < 3e-6 * abs(float(loss)) and abs(float(psnr_a) - float(psnr)) < 1e-4
+    for n, gd in zip((net_c, net_f), g_direct):
+        assert float((n.flat.grad - gd).norm() / gd.norm()) < 3e-5
+
+
 def test_direct_spin_iteration_bf16_runs_on_the_merged_backward():
     """bf16 (the bench's precision): the direct iteration's gradients against the autograd route's, which runs the three
     renders one after the other; the two differ only by the split-K partition of the bf16 partial sums (documented 6e-3)."""
