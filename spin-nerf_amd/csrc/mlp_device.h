@@ -81,6 +81,7 @@ template <int P, int WAVES_> struct Pipe {
   unsigned long long t_wait = 0, t_bar = 0, n_acq = 0, t_start = 0;
 #endif
   int pend;          // DMA pieces of the block being issued that are still to be issued
+  bool dma_on = true; // (SNR_ABLATE & 64)
   const char* pend_src;
   char* pend_dst;
 
@@ -110,6 +111,9 @@ template <int P, int WAVES_> struct Pipe {
 #if SNR_ABLATE & 8   // timing experiment: no DMA
     pend = 0;
 #endif
+#if SNR_ABLATE & 64  // timing experiment (round 5): DMA during a workgroup's FIRST pass only — later passes multiply with the real
+    if (!dma_on) pend = 0;   // (wrong-stage) weights the ring then holds, not with whatever an un-written LDS contains: the
+#endif                       // "no DMA" build above measures zero operands at a higher clock, not the DMA (profiles/r05_chain_ab.txt)
     if (pend > 0) {
       // One wait state in front of the DMA.  Measured on MI355X: with an (asm) ds_read issued in the cycle
       // before it, the DMA occasionally went out with a corrupt global address (memory fault with the upper

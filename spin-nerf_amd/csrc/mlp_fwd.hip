@@ -367,6 +367,9 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
         }
       }
     }
+#if SNR_ABLATE & 64
+    pipe.dma_on = false;
+#endif
   }
   pipe.drain();  // prefetched blocks still in flight must land before the LDS allocation is released
 }
