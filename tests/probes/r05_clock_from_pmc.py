@@ -5,7 +5,7 @@ acc = collections.defaultdict(list)
 for f in glob.glob((sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r05_c2_pmc") + "/c/**/*counter_collection.csv", recursive=True) + \
          glob.glob((sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r05_c2_pmc") + "/c/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and ("mlp_fwd" in r["Kernel_Name"] or "mlp_dgrad" in r["Kernel_Name"]):
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and "snr::" in r["Kernel_Name"]:
             k = r["Kernel_Name"].replace("void ", "").replace("snr::", "").split("(")[0]
             dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
             acc[k].append((float(r["Counter_Value"]) / 8.0 / dur, dur))
