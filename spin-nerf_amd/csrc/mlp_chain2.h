@@ -14,8 +14,9 @@
 // HYPOTHESIS the structure was built to test: the shipped kernels' +13 ... +32 % (weight DMA) and +20 ... +48 % (saved-tensor
 // stores) are time the ISSUING wave spends stuck at a vector-memory instruction with its MFMA chain stopped; a helper stuck
 // there stops nobody.  OUTCOME (profiles/r05_chain_ab.txt): refuted.  Results are bit-identical, the kernels are 7-11 % slower:
-// a DMA piece costs the compute waves the same whether a helper issues it or they do — it is LDS traffic every fragment read
-// shares —, and the 168-register budget, the spill traffic and the progress words cost a further 8 %.  The code stays behind
+// a DMA piece costs the same whether a helper issues it or the compute waves do — the weight stream is paid in CLOCK on this
+// power-limited part (3 % in cycles, 10 % in effective shader clock with real-valued weights; section 5b of that file) and in
+// LDS traffic every fragment read shares —, and the 168-register budget, the spill traffic and the progress words cost a further 8 %.  The code stays behind
 // SNR_CHAIN2=1 (default 0) as the experiment's record and A/B switch; tests/test_gpu_chain2.py holds it bit-identical.
 //
 // Registers: a tile's input (64) and output (64) do not fit 168 next to accumulator, bias and fragment window, so the output
