@@ -120,7 +120,10 @@ template <int P, int WAVES_> struct Pipe {
       // address half zero, ~1 launch in 2 of the fp32 kernel; never with the s_nop).  The compiler separates
       // the two when it knows both instructions; it cannot see into the asm.
       asm volatile("s_nop 0");
-      __builtin_amdgcn_global_load_lds(pend_src + (size_t)lane_off, SNR_LDS(pend_dst), 16, 0, 0);
+#ifndef SNR_DMA_AUX
+#define SNR_DMA_AUX 0   // A/B builds: cache policy bits of the weight stream's LDS-DMA (1 sc0, 2 nt, 16 sc1)
+#endif
+      __builtin_amdgcn_global_load_lds(pend_src + (size_t)lane_off, SNR_LDS(pend_dst), 16, 0, SNR_DMA_AUX);
       pend_src += WAVES * 1024;
       pend_dst += WAVES * 1024;
       --pend;
