@@ -61,6 +61,17 @@ def _keep_listings(verbose):
             print(r.stdout.strip()[-2000:], flush=True)
         if r.returncode:
             raise RuntimeError("check_lds_asm.py: an asm LDS read is consumed before its wait (or no kernel was recognised)")
+        # register spills of the weight-gradient kernels must stay out of their tile loops (tools/check_spills.py: no scratch_* /
+        # v_writelane / v_readlane inside an innermost loop that contains MFMAs; the chain kernels' only MFMA loop is the pass
+        # loop around the whole unrolled network, so the criterion does not apply to them: reported, not gated)
+        tool = os.path.join(os.path.dirname(HERE), "tools", "check_spills.py")
+        for lst in listings:
+            r = subprocess.run([sys.executable, tool, lst, "mlp_wgrad_pair_kernel", "mlp_wgrad_kernelILi0"],
+                               capture_output=True, text=True)
+            if verbose or r.returncode:
+                print(r.stdout.strip()[-2000:], flush=True)
+            if r.returncode:
+                raise RuntimeError("check_spills.py: a register spill sits inside a tile loop of a weight-gradient kernel")
 
 
 def build(force=False, verbose=True):

@@ -111,3 +111,26 @@ def test_checker_does_not_vouch_for_a_global_load_used_behind_a_branch(tmp_path)
     before = chk.unverified[0]
     assert chk.check(_listing(tmp_path, body)) == 0
     assert chk.unverified[0] == before + 1
+
+
+def test_spill_checker_tells_a_tile_loop_from_the_prologue(tmp_path):
+    """tools/check_spills.py (round 5): a spill inside an innermost loop that contains MFMAs is a per-tile
+    cost and fails the named kernel; the same spill in the prologue does not.  The built library's listing: the pair kernel's
+    51 scratch operations and 215 SGPR-spill lane moves all sit outside its 14 tile loops."""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_spills.py")
+    head = "_Z6kernelv:                             ; @_Z6kernelv\n"
+    loop = ".LBB0_1:\n\tv_mfma_f32_32x32x16_bf16 v[16:31], v[0:3], v[40:43], v[16:31]\n%s\ts_cbranch_scc1 .LBB0_1\n"
+    tail = "\ts_endpgm\n.Lfunc_end0:\n"
+    spill = "\tscratch_store_dword off, v2, off offset:4\n"
+    good = tmp_path / "good.s"; good.write_text(head + spill + loop % "" + tail)
+    bad = tmp_path / "bad.s"; bad.write_text(head + loop % spill + tail)
+    assert subprocess.run([sys.executable, tool, str(good), "kernel"]).returncode == 0
+    assert subprocess.run([sys.executable, tool, str(bad), "kernel"]).returncode == 1
+    lst = os.path.join(ROOT, "spin-nerf_amd", "lib", "mlp_bwd.gfx950.s")
+    if os.path.exists(lst):
+        r = subprocess.run([sys.executable, tool, lst, "mlp_wgrad_pair_kernel", "mlp_wgrad_kernelILi0"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout
+        assert "mlp_wgrad_pair_kernel" in r.stdout and "(in an innermost MFMA loop: 0)" in r.stdout
+
