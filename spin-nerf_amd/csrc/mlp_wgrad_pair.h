@@ -48,7 +48,6 @@ struct PairJob {
   int64_t flag_off;        // ReLU flags of layer 2k in the forward workspace ([n_tiles][1 KiB])
   int x_ks;                // 16 (hidden layer) or 4 (positional encoding)
   int slot_begin, n_splits;   // pair slots [slot_begin, slot_begin + n_splits): slot p = workgroups (16 (p / 8) + p % 8) + {0, 8}
-  int wg_begin[2], n_split[2];   // (unpaired launch) kind A = workgroups [wg_begin[0], + n_split[0]), kind B = [wg_begin[1], + n_split[1])
   PairHalf a, b;
   // (round 4) one launch serves the layer pairs of SEVERAL networks (coarse + fine): every job carries its network's buffers
   const char* act;         // forward workspace
@@ -65,7 +64,6 @@ struct PairArgs {
   PairJob job[kMaxPairs];
   PlainJob plain[kMaxPlain];  // the jobs of the plain split-K pass (mlp_wgrad.h), run by the launch's workgroups beyond the pair slots
   int n_slots;                // pair slots of the launch
-  int unpaired, n_pair_wgs;   // (round 5) unpaired: the first n_pair_wgs workgroups are the kinds' (PairJob::wg_begin), the rest plain
   int n_plain_wgs;            // plain workgroups of the launch
 #ifdef SNR_PAIR_DEBUG
   int only_kind, only_pair;   // timing experiments (SNR_PAIR_KIND / SNR_PAIR_PAIR; debug builds only): -1 = all
@@ -316,7 +314,7 @@ __device__ __forceinline__ void pk_sum_bf16_2(float& sum, unsigned x0, unsigned 
 }
 // WV: the wave index as a compile-time constant (kind A: which row tiles' sums this wave keeps is decided without branches)
 template <int TYPE, int KX, int WV>
-__device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, int split, int nsp, char* smem, int wave, int lane) {
+__device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, int split, char* smem, int wave, int lane) {
   using C = PairCfg<TYPE, KX>;
   using Frag = bf16x8;
   constexpr bool PB = C::PB;
@@ -326,7 +324,7 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
   const PairHalf& H = PB ? J.b : J.a;
 
   // tiles split, split + n_splits, ... (the same sequence in the kind-A and the kind-B workgroup of a slot)
-  const int64_t tstep = nsp;   // splits of this kind (paired launch: J.n_splits for both)
+  const int64_t tstep = J.n_splits;
   const int64_t t1 = (J.n_tiles - split + tstep - 1) / tstep;   // >= 1: the host never makes more splits than tiles
 
   // ---- DMA: this wave's pieces wave + 4 k of X and of D, and its quarter of the flag KiB -------------------------------
@@ -717,19 +715,9 @@ __global__ __launch_bounds__(64 * kPairWaves) void mlp_wgrad_pair_kernel(PairArg
   // a PLAIN workgroup (the split-K jobs of mlp_wgrad.h: stream-bound work on its own CUs beside the matrix-bound slots),
   // numbered in block order.
   const int b = blockIdx.x;
-  int grp = b >> 4, kind = (b >> 3) & 1, col = b & 7;
+  const int grp = b >> 4, kind = (b >> 3) & 1, col = b & 7;
   const int p = grp * 8 + col;
-  if (a.unpaired) {
-    // (round 5) every kind of every layer pair has its own run of workgroups, as many as its weight earns it
-    if (b >= a.n_pair_wgs) {
-      const int q = b - a.n_pair_wgs;
-      if (q >= a.n_plain_wgs) return;
-      int qi = 0;
-      while (qi + 1 < a.n_plain && a.plain[qi + 1].j.split_begin <= q) ++qi;
-      plain_job_run(a.plain[qi], q - a.plain[qi].j.split_begin, smem, wave, lane);
-      return;
-    }
-  } else if (p >= a.n_slots) {
+  if (p >= a.n_slots) {
     const int full = a.n_slots >> 3, rem = a.n_slots & 7;
     const int q = grp == full ? kind * (8 - rem) + (col - rem) : (rem ? 2 * (8 - rem) : 0) + (b - 16 * (full + (rem ? 1 : 0)));
     if (q >= a.n_plain_wgs) return;
@@ -742,37 +730,34 @@ __global__ __launch_bounds__(64 * kPairWaves) void mlp_wgrad_pair_kernel(PairArg
     return;
   }
   int ji = 0;
-  if (a.unpaired) { while (ji + 1 < a.n_pairs && a.job[ji + 1].wg_begin[0] <= b) ++ji; }
-  else { while (ji + 1 < a.n_pairs && a.job[ji + 1].slot_begin <= p) ++ji; }
+  while (ji + 1 < a.n_pairs && a.job[ji + 1].slot_begin <= p) ++ji;
   const PairJob& J = a.job[ji];
-  if (a.unpaired) kind = b >= J.wg_begin[1] ? 1 : 0;
-  const int split = a.unpaired ? b - J.wg_begin[kind] : p - J.slot_begin;
-  const int nsp = a.unpaired ? J.n_split[kind] : J.n_splits;
-  if (split >= nsp) return;                      // (slots beyond the last job)
+  const int split = p - J.slot_begin;
+  if (split >= J.n_splits) return;               // (slots beyond the last job)
 #ifdef SNR_PAIR_DEBUG
   if (a.only_kind == 2 || (a.only_kind >= 0 && a.only_kind < 2 && kind != a.only_kind) || (a.only_pair >= 0 && ji != a.only_pair)) return;
 #endif
   // kind A is compiled once per wave (its row sums), kind B once
 #define SNR_PAIR_A(KX_) \
   do { \
-    if (wave == 0) pair_run<0, KX_, 0>(a, J, split, nsp, smem, wave, lane); \
-    else if (wave == 1) pair_run<0, KX_, 1>(a, J, split, nsp, smem, wave, lane); \
-    else if (wave == 2) pair_run<0, KX_, 2>(a, J, split, nsp, smem, wave, lane); \
-    else pair_run<0, KX_, 3>(a, J, split, nsp, smem, wave, lane); \
+    if (wave == 0) pair_run<0, KX_, 0>(a, J, split, smem, wave, lane); \
+    else if (wave == 1) pair_run<0, KX_, 1>(a, J, split, smem, wave, lane); \
+    else if (wave == 2) pair_run<0, KX_, 2>(a, J, split, smem, wave, lane); \
+    else pair_run<0, KX_, 3>(a, J, split, smem, wave, lane); \
   } while (0)
 #ifdef SNR_PAIR_ONLY   // register-allocation experiments: one instance per build
-  if (SNR_PAIR_ONLY == 0) pair_run<0, 16, 1>(a, J, split, nsp, smem, wave, lane);
-  if (SNR_PAIR_ONLY == 1) pair_run<1, 16, 0>(a, J, split, nsp, smem, wave, lane);
-  if (SNR_PAIR_ONLY == 2) pair_run<0, 4, 1>(a, J, split, nsp, smem, wave, lane);
-  if (SNR_PAIR_ONLY == 3) pair_run<1, 4, 0>(a, J, split, nsp, smem, wave, lane);
+  if (SNR_PAIR_ONLY == 0) pair_run<0, 16, 1>(a, J, split, smem, wave, lane);
+  if (SNR_PAIR_ONLY == 1) pair_run<1, 16, 0>(a, J, split, smem, wave, lane);
+  if (SNR_PAIR_ONLY == 2) pair_run<0, 4, 1>(a, J, split, smem, wave, lane);
+  if (SNR_PAIR_ONLY == 3) pair_run<1, 4, 0>(a, J, split, smem, wave, lane);
   return;
 #endif
   if (J.x_ks == 16) {
     if (kind == 0) SNR_PAIR_A(16);
-    else pair_run<1, 16, 0>(a, J, split, nsp, smem, wave, lane);
+    else pair_run<1, 16, 0>(a, J, split, smem, wave, lane);
   } else {
     if (kind == 0) SNR_PAIR_A(4);
-    else pair_run<1, 4, 0>(a, J, split, nsp, smem, wave, lane);
+    else pair_run<1, 4, 0>(a, J, split, smem, wave, lane);
   }
 #undef SNR_PAIR_A
 }
@@ -858,26 +843,9 @@ inline int make_wgall_plan(WgNet* nets, int n_nets, WgAllPlan& Pl) {
   int psplit[kMaxPairs], qsplit[kMaxPlain];
   apportion(pw, pcap, np, n_slots, psplit);
   apportion(qw, qcap, nq, n_plain, qsplit);
-  // (round 5, SNR_PAIR_UNPAIRED=1) kind A's body is shorter than kind B's and a slot's kind-A workgroup idles while its
-  // partner finishes: instead of one workgroup of each kind per slot, the 2 x n_slots workgroups go to the 2 x np
-  // (layer pair, kind) jobs by weight.  The two kinds of a pair then sweep different tile sequences: no pacing, and the
-  // second fetch of a tile no longer finds it in the XCD's L2.
-  const bool unpaired = tunables().pair_unpaired != 0;
-  int ksplit[2 * kMaxPairs];
-  if (unpaired) {
-    int64_t kw[2 * kMaxPairs], kcap[2 * kMaxPairs];
-    const int wa = tunables().pair_wa, w0a = tunables().pair_w0a, w0b = tunables().pair_w0b;
-    for (int j = 0; j < np; ++j) {
-      const bool first = (j % 4) == 0;   // (four layer pairs per network, pair 0 first)
-      kw[2 * j] = (int64_t)(first ? w0a : wa) * pcap[j];
-      kw[2 * j + 1] = (int64_t)(first ? w0b : 100) * pcap[j];
-      kcap[2 * j] = kcap[2 * j + 1] = pcap[j];
-    }
-    apportion(kw, kcap, 2 * np, 2 * n_slots, ksplit);
-  }
 
   // ---- placement: plain workgroups / pair slots in job order; every network's partial planes in its own buffer ----
-  int slot = 0, qwg = 0, pwg = 0;
+  int slot = 0, qwg = 0;
   for (int i = 0; i < n_nets; ++i) {
     WgNet& N = nets[i];
     const snr_mlp_config* c = N.c;
@@ -918,25 +886,19 @@ inline int make_wgall_plan(WgNet* nets, int n_nets, WgAllPlan& Pl) {
       J.n_tiles = AL.n_tiles;
       const int64_t s = psplit[Pl.pair_job0[i] + k];
       J.slot_begin = slot; J.n_splits = (int)s; slot += (int)s;
-      int64_t sa = s, sb = s;   // planes of kind A / kind B
-      if (unpaired) {
-        sa = ksplit[2 * (Pl.pair_job0[i] + k)]; sb = ksplit[2 * (Pl.pair_job0[i] + k) + 1];
-        J.wg_begin[0] = pwg; J.n_split[0] = (int)sa; pwg += (int)sa;
-        J.wg_begin[1] = pwg; J.n_split[1] = (int)sb; pwg += (int)sb;
-      }
       const int NMb = J.x_ks / 2;
       J.a.w_frag = T.e[la].frag_begin;
       J.a.bias_off = bias_off_stage(la);
       J.b.w_frag = T.e[n_fwd_entries + n_top_bwd + (7 - lb)].frag_begin;
       J.b.bias_off = 0;
-      J.a.part_off = po; po += sa * 256 * 256;
-      J.a.bias_part_off = po; po += sa * 256;
-      J.b.part_off = po; po += sb * 256 * 32 * NMb;
-      J.b.bias_part_off = po; po += sb * 256;
+      J.a.part_off = po; po += s * 256 * 256;
+      J.a.bias_part_off = po; po += s * 256;
+      J.b.part_off = po; po += s * 256 * 32 * NMb;
+      J.b.bias_part_off = po; po += s * 256;
       // reduce table: kind A planes [row = d z_{lb} slot][column j of h_{la} (true order)] -> dW_{lb}[true(row)][j], row sums -> db_{lb}
-      auto rjob = [&](int nta, int ntb, int64_t part_off, int64_t bias_part_off, int64_t planes) {
+      auto rjob = [&](int nta, int ntb, int64_t part_off, int64_t bias_part_off) {
         WgradJob& Q = R.job[nj];
-        Q.nta = nta; Q.ntb = ntb; Q.n_splits = (int)planes; Q.split_begin = 0; Q.part_off = part_off; Q.bias_part_off = bias_part_off;
+        Q.nta = nta; Q.ntb = ntb; Q.n_splits = (int)s; Q.split_begin = 0; Q.part_off = part_off; Q.bias_part_off = bias_part_off;
         return nj++;
       };
       auto rout = [&](int j, int rows, int a_kind, int cols, int b_kind, int Lenc, int64_t w_off, int ld, int col_off,
@@ -947,10 +909,10 @@ inline int make_wgall_plan(WgNet* nets, int n_nets, WgAllPlan& Pl) {
         O.bias_off = (int)bias_off; O.to_scratch = 0;
       };
       const int ld_b = lb == kSkip + 1 ? kW + ip : kW, co_b = lb == kSkip + 1 ? ip : 0;
-      int j = rjob(8, 8, J.a.part_off, J.a.bias_part_off, sa);
+      int j = rjob(8, 8, J.a.part_off, J.a.bias_part_off);
       rout(j, kW, SRC_H, kW, SRC_NAT, 0, L.w_pts[lb], ld_b, co_b, kW, kW, L.b_pts[lb]);
       // kind B planes [neuron n of layer la (true order)][row = X slot] -> dW_{la}[n][true(row)], column sums -> db_{la}
-      j = rjob(8, NMb, J.b.part_off, J.b.bias_part_off, sb);
+      j = rjob(8, NMb, J.b.part_off, J.b.bias_part_off);
       if (k == 0) rout(j, kW, SRC_NAT, 32 * NMb, SRC_ENC_PTS, L_pts, L.w_pts[la], ip, 0, kW, ip, L.b_pts[la]);
       else rout(j, kW, SRC_NAT, 32 * NMb, SRC_H, 0, L.w_pts[la], kW, 0, kW, kW, L.b_pts[la]);
     }
@@ -965,12 +927,10 @@ inline int make_wgall_plan(WgNet* nets, int n_nets, WgAllPlan& Pl) {
   const int full = slot >> 3, rem = slot & 7;
   const int in_group = rem ? 2 * (8 - rem) : 0;
   Pl.grid = 16 * (full + (rem ? 1 : 0)) + (qwg > in_group ? qwg - in_group : 0);
-  A.unpaired = unpaired ? 1 : 0; A.n_pair_wgs = pwg;
-  if (unpaired) Pl.grid = pwg + qwg;
 #ifdef SNR_PAIR_DEBUG
   A.only_kind = tunables().only_kind; A.only_pair = tunables().only_pair;
 #endif
-  A.sync_period = unpaired ? 0 : tunables().pair_poll; A.sync_lead = tunables().pair_lead;
+  A.sync_period = tunables().pair_poll; A.sync_lead = tunables().pair_lead;
   return SNR_OK;
 }
 
@@ -981,10 +941,7 @@ inline void fill_wgall_pointers(WgAllPlan& Pl, const WgNet* nets, int i, const c
   for (int k = 0; k < 4; ++k) {
     PairJob& J = Pl.pa.job[Pl.pair_job0[i] + k];
     J.act = act; J.ws = ws; J.blob = blob; J.bias = bias; J.part = part;
-    // (unpaired launch: nobody reads the words; kind B's store per body stays — a branch around it would cut the body in two —
-    //  and lands in the network's kSyncWords words: a network never has more than 2 x kMaxPairSlots pair workgroups)
-    J.sync = (unsigned*)(part + N.sync_off) + (Pl.pa.unpaired ? J.wg_begin[1] - Pl.pa.job[Pl.pair_job0[i]].wg_begin[0]
-                                                               : J.slot_begin - Pl.pa.job[Pl.pair_job0[i]].slot_begin);
+    J.sync = (unsigned*)(part + N.sync_off) + (J.slot_begin - Pl.pa.job[Pl.pair_job0[i]].slot_begin);
   }
   for (int j = 0; j < N.plain.n_jobs; ++j) {
     PlainJob& Q = Pl.pa.plain[Pl.plain_job0[i] + j];

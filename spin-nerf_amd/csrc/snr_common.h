@@ -60,9 +60,6 @@ struct Tunables {
   int plain_wgs;             // SNR_PLAIN_WGS: plain workgroups inside the layer-pair launch (0 = the CUs the slots leave)
   int pair_w0;               // SNR_PAIR_W0: slot weight of pair 0 (others = 100)
   int pair_poll, pair_lead;  // SNR_PAIR_POLL / SNR_PAIR_LEAD: pacing of the two kinds of a slot
-  int pair_unpaired;         // SNR_PAIR_UNPAIRED: 1 = the two kinds of a layer pair get their own numbers of workgroups (by
-                             // weight) instead of one of each per slot; no pacing, no L2 sharing of the fetch
-  int pair_wa, pair_w0a, pair_w0b;   // SNR_PAIR_WA / _W0A / _W0B: cost per tile of kind A, of pair 0's kinds (kind B of a trunk pair = 100)
   int only_kind, only_pair;  // SNR_PAIR_KIND / SNR_PAIR_PAIR (debug builds of the pair kernel only)
   int merge_nets;            // SNR_MERGE_NETS=0: one backward launch sequence per network (A/B against the merged one)
   int chain_grid;            // SNR_CHAIN_GRID: workgroups of a chain-kernel launch (the rest grid-stride); 0 = default
@@ -79,10 +76,6 @@ inline Tunables read_tunables() {
   t.pair_w0 = geti("SNR_PAIR_W0", 0);
   t.pair_poll = geti("SNR_PAIR_POLL", 16);
   t.pair_lead = geti("SNR_PAIR_LEAD", 2);
-  t.pair_unpaired = geti("SNR_PAIR_UNPAIRED", 0);
-  t.pair_wa = geti("SNR_PAIR_WA", 93);
-  t.pair_w0a = geti("SNR_PAIR_W0A", 76);
-  t.pair_w0b = geti("SNR_PAIR_W0B", 84);
   t.only_kind = geti("SNR_PAIR_KIND", -1);
   t.only_pair = geti("SNR_PAIR_PAIR", -1);
   t.merge_nets = geti("SNR_MERGE_NETS", 1);

@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B of the layer-pair launch: one workgroup of each kind per slot (shipped) against workgroups per (pair, kind) by weight
+# A/B of the layer-pair launch: one workgroup of each kind per slot (shipped) against workgroups per (pair, kind) by weight.
+# Needs the experiment's kernel (commit c990628, `git show c990628:spin-nerf_amd/csrc/mlp_wgrad_pair.h`): the switch was
+# removed again after it measured nothing (profiles/r05_pair_unpaired_ab.txt).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 SNR_PAIR_UNPAIRED=1 timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_train_step.py -m gpu -x -q -k "backward or wgrad or gradient or step" 2>&1 | tail -3
 B="python bench.py --steps 30 --warmup 5 --blocks 3 --no-cpu-baseline --no-frame --no-hashgrid"
