@@ -102,13 +102,21 @@ def launch_ranks(n):
     process; returns the exit code.  The parent never initialises the GPU."""
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    for attempt in range(3):
+        # a free port: bound, read, released — another process can take it before the launcher binds it (ADVICE r04), so a
+        # rendezvous that fails on "address already in use" is tried again on a fresh port
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(r.stderr)
+        taken = any(t in r.stderr.lower() for t in ("address already in use", "eaddrinuse"))
+        if r.returncode == 0 or not taken:
+            break
+        print(f"bench.py: port {port} was taken before the launcher bound it; retrying", file=sys.stderr)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     for l in r.stdout.splitlines():
         if not l.startswith("{"):
