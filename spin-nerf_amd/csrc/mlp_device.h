@@ -10,6 +10,10 @@ namespace snr {
 // weight-chunk pipeline
 // ------------------------------------------------------------------------------------------
 constexpr int kBiasLdsBytes = 12288;  // >= 2496 floats
+#ifndef SNR_IN_PREFETCH
+#define SNR_IN_PREFETCH 0   // A/B builds (round 5): 1 = the forward kernel fetches a pass's inputs through LDS one pass ahead, persistent
+#endif                      // grid.  Measured: nothing (profiles/r05_fwd_prologue_ab.txt) — the loads' latency was never the cost
+
 
 // a*b + c with the product rounded first (HIP's __fmul_rn/__fadd_rn are plain operators and would
 // be contracted into one FMA)
@@ -505,6 +509,69 @@ __device__ __forceinline__ void encode(float x, float y, float z, int L, int g, 
     }
     out[q] = f;
   }
+}
+
+// The same encoding with the number of frequencies known at compile time (bf16 only; the reference's configurations use
+// multires = 10 / multires_views = 4: run_nerf.py:808-811) — round 5.  The generic version above derives, PER PAIR and at run
+// time, which frequency and axis the lane's half g owns (p / 3, p % 3, 2^k by v_ldexp, the p < 3 L tests): ~28 instructions a
+// pair, 450 per positional encoding, three encodings a pass — and the two waves of a SIMD run them at the same moment (the
+// waves of a workgroup move through the weight stream in lockstep), so the matrix pipe idles meanwhile.  Here the two
+// candidates of every pair (g = 0 / 1) are compile-time constants and the lane picks with one v_cndmask each: input
+// coordinate, scale 2^k / 2 pi (ONE multiplication: scaling by a power of two is exact, so fl(x 2^k c) is the same number the
+// generic version rounds to — the results are bit-identical, tests/test_gpu_kernels.py), then floor / sub / sin / cos.
+template <int P, int KS, int LT>
+__device__ __forceinline__ void encode_static(float x, float y, float z, int g, typename Mma<P>::Frag* out) {
+  static_assert(P == kBF16, "hardware sin / cos: bf16 mode only");
+  constexpr int HP = Prec<P>::EPF / 2;
+  asm volatile("" : "+v"(g));   // (as above: nothing here may be hoisted out of the kernel's main loop and held across it)
+  const bool hi = g != 0;
+  static_for<0, KS>([&](auto Q_) {
+    constexpr int q = decltype(Q_)::value;
+    typename Mma<P>::Frag f = Mma<P>::zero();
+    static_for<0, HP>([&](auto PP_) {
+      constexpr int pp = decltype(PP_)::value;
+      constexpr int p0 = (2 * q) * HP + pp, p1 = (2 * q + 1) * HP + pp;
+      // 0: a (sin, cos) pair; 1: (x, y); 2: (z, pad); 3: padding
+      constexpr int kind0 = p0 < 3 * LT ? 0 : (p0 == 3 * LT ? 1 : (p0 == 3 * LT + 1 ? 2 : 3));
+      constexpr int kind1 = p1 < 3 * LT ? 0 : (p1 == 3 * LT ? 1 : (p1 == 3 * LT + 1 ? 2 : 3));
+      float s = 0.f, c = 0.f;
+      if constexpr (kind0 == 0 || kind1 == 0) {
+        // (a lane whose own candidate is not a sin / cos pair computes the other half's: finite, and replaced below)
+        constexpr int k0 = kind0 == 0 ? p0 / 3 : p1 / 3, ax0 = kind0 == 0 ? p0 % 3 : p1 % 3;
+        constexpr int k1 = kind1 == 0 ? p1 / 3 : k0, ax1 = kind1 == 0 ? p1 % 3 : ax0;
+        constexpr float C0 = 0.15915494309189535f * (float)(1 << k0), C1 = 0.15915494309189535f * (float)(1 << k1);
+        const float in0 = ax0 == 0 ? x : (ax0 == 1 ? y : z), in1 = ax1 == 0 ? x : (ax1 == 1 ? y : z);
+        const float in = ax0 == ax1 ? in0 : (hi ? in1 : in0);
+        const float sc = k0 == k1 ? C0 : (hi ? C1 : C0);
+        float rev = in * sc;
+        rev = rev - __builtin_floorf(rev);
+        s = __builtin_amdgcn_sinf(rev);
+        c = __builtin_amdgcn_cosf(rev);
+      }
+      if constexpr (kind0 != 0) {
+        const float s0 = kind0 == 1 ? x : (kind0 == 2 ? z : 0.f), c0 = kind0 == 1 ? y : 0.f;
+        s = hi ? s : s0; c = hi ? c : c0;
+      }
+      if constexpr (kind1 != 0) {
+        const float s1 = kind1 == 1 ? x : (kind1 == 2 ? z : 0.f), c1 = kind1 == 1 ? y : 0.f;
+        s = hi ? s1 : s; c = hi ? c1 : c;
+      }
+      Mma<P>::set(f, 2 * pp, s);
+      Mma<P>::set(f, 2 * pp + 1, c);
+    });
+    out[q] = f;
+  });
+}
+// bf16 with the reference's frequency counts takes the static version (a wave-uniform branch); everything else the generic one
+template <int P, int KS, int LT>
+__device__ __forceinline__ void encode_auto(float x, float y, float z, int L, int g, typename Mma<P>::Frag* out) {
+#ifndef SNR_ENC_STATIC
+#define SNR_ENC_STATIC 1   // A/B builds: 0 = the generic encoding everywhere
+#endif
+  if constexpr (P == kBF16 && SNR_ENC_STATIC) {
+    if (L == LT) { encode_static<P, KS, LT>(x, y, z, g, out); return; }
+  }
+  encode<P, KS>(x, y, z, L, g, out);
 }
 
 }  // namespace snr

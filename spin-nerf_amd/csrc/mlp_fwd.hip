@@ -114,6 +114,40 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int sj = lane & 31, g = lane >> 5;   // sample within a 32-sample tile, lane half
 
+  // ---- (round 5 experiment, SNR_IN_PREFETCH=1; off by default) a pass's per-sample inputs through LDS, one pass ahead -----
+  // t = z_vals[m], the ray's origin and direction, its view direction: ten floats per sample behind a dependent chain
+  // (sample -> ray -> row) of global loads at the top of every pass.  An ablation without those loads was 5 % (training
+  // forward) / 8 % (frame) faster — but it also fed the network smooth positions, and the gain was the CLOCK of quieter
+  // operands: with the real inputs prefetched as below the forward is 0.275 against 0.279 ms and the frame 42.9 against
+  // 42.6 ms (profiles/r05_fwd_prologue_ab.txt).  The mechanism, for the record: each wave
+  // fetches its next tile's ten fields with five LDS-DMA dwords per lane (lane (sample, half g), instruction i: field
+  // 2 i + g — 0 = t, 1..6 = the ray's row, 7..9 = the view direction — lands at dword 64 i + lane of the wave's staging
+  // area) while the current pass multiplies, and reads them back at the top of the next pass (field f of sample s =
+  // dword 32 f + s).  The first pass's fetch is issued before the bias copy and the ring fill, under their latency.
+  // Only the issuing wave reads its area: its own counted vmcnt wait orders the two.
+  constexpr int kInBytes = 5 * 256;
+  char* const in_stage = smem + kBiasLdsBytes + kRingBytes + wave * (NJ * kInBytes);
+  const bool small_n = SNR_ENC_STATIC && a.n_samples <= 0x7fffffffll;   // 32-bit sample -> ray division (the 64-bit one: ~100 instructions)
+  const bool staged = SNR_IN_PREFETCH && a.pts == nullptr;
+  auto prefetch_inputs = [&](int64_t wgn) {
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+      int64_t mt = ((wgn * WAVES + wave) * NJ + jt) * 32 + sj;
+      if (mt >= a.n_samples) mt = a.n_samples - 1;   // (a tile's tail beyond n_samples is masked by `valid`: any readable sample)
+      const int64_t ray = small_n ? (int64_t)((uint32_t)mt / (uint32_t)a.S) : mt / a.S;
+      const float* pr = a.rays + ray * a.ray_ld;
+      const float* pv = VD ? a.viewdirs + ray * a.vd_ld : pr;
+      const float* src[5] = {g ? pr : a.z_vals + mt, pr + 1 + g, pr + 3 + g, g ? pv : pr + 5, pv + 1 + g};
+      char* dst = in_stage + jt * kInBytes;
+#pragma unroll
+      for (int i = 0; i < (VD ? 5 : 4); ++i) {
+        asm volatile("s_nop 0");   // (no LDS read in the cycle in front of an LDS-DMA: mlp_device.h, Pipe::issue_one)
+        __builtin_amdgcn_global_load_lds(src[i], SNR_LDS(dst + 256 * i), 4, 0, 0);
+      }
+    }
+  };
+  if (staged) prefetch_inputs(blockIdx.x);
+
   for (int i = tid; i < a.bias_floats; i += 64 * WAVES) bias_lds[i] = a.bias[i];
 
   Pipe<P, WAVES> pipe;
@@ -138,9 +172,35 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     for (int jt = 0; jt < NJ; ++jt) {
       m[jt] = (tile0 + jt) * 32 + sj;
       valid[jt] = m[jt] < a.n_samples;
-      const int64_t ray = valid[jt] ? m[jt] / a.S : 0;
       px[jt] = py[jt] = pz[jt] = dx[jt] = dy[jt] = dz[jt] = 0.f;
+      if (staged) {
+        // everything older than the youngest PIECES x kDepth vector-memory operations of this wave has completed: the fetch of
+        // these fields is older (behind it: the ring fill / at least four blocks' pieces of the previous pass)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Pipe<P, WAVES>::PIECES * kDepth) : "memory");
+        const uint32_t ia = lds_addr(in_stage + jt * kInBytes) + 4u * (uint32_t)sj;
+        float f[10];
+#define SNR_IN_RD(I) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f[I]) : "v"(ia), "n"(128 * (I)))
+        SNR_IN_RD(0); SNR_IN_RD(1); SNR_IN_RD(2); SNR_IN_RD(3); SNR_IN_RD(4); SNR_IN_RD(5); SNR_IN_RD(6);
+        if constexpr (VD) { SNR_IN_RD(7); SNR_IN_RD(8); SNR_IN_RD(9); }
+#undef SNR_IN_RD
+        if constexpr (VD) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]));
+        if (valid[jt]) {
+          // run_nerf.py:670-671; separate multiply and add (no FMA) so pts round like the reference's
+          px[jt] = mul_add_unfused(f[4], f[0], f[1]);
+          py[jt] = mul_add_unfused(f[5], f[0], f[2]);
+          pz[jt] = mul_add_unfused(f[6], f[0], f[3]);
+          if constexpr (VD) { dx[jt] = f[7]; dy[jt] = f[8]; dz[jt] = f[9]; }
+        }
+        continue;
+      }
+      // (the ray of a sample: a 32-bit division where the launch allows it)
+      const int64_t ray = !valid[jt] ? 0 : (small_n ? (int64_t)((uint32_t)m[jt] / (uint32_t)a.S) : m[jt] / a.S);
       if (valid[jt]) {
+#if SNR_ABLATE & 256   // timing experiment (round 5): no global loads in the pass prologue (positions from the sample index)
+        px[jt] = 1e-6f * (float)(int)m[jt]; py[jt] = 0.5f * px[jt]; pz[jt] = 1.f - px[jt];
+        if constexpr (VD) { dx[jt] = px[jt]; dy[jt] = py[jt]; dz[jt] = pz[jt]; }
+#else
         if (a.pts) {
           px[jt] = a.pts[3 * m[jt]]; py[jt] = a.pts[3 * m[jt] + 1]; pz[jt] = a.pts[3 * m[jt] + 2];
         } else {
@@ -155,6 +215,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
           const float* v = a.viewdirs + ray * a.vd_ld;
           dx[jt] = v[0]; dy[jt] = v[1]; dz[jt] = v[2];
         }
+#endif
       }
     }
     // Encodings.  With two waves per SIMD (256 registers each) they are not kept across the trunk:
@@ -168,7 +229,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
       for (int jt = 0; jt < NJ; ++jt) {
         float x = px[jt], y = py[jt], z = pz[jt];
         if (fresh) asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-        encode<P, KS_PE>(x, y, z, a.multires, g, pe[jt]);
+        encode_auto<P, KS_PE, kMaxMultires>(x, y, z, a.multires, g, pe[jt]);
       }
     };
     auto make_dir = [&](bool fresh) {
@@ -177,7 +238,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
         for (int jt = 0; jt < NJ; ++jt) {
           float x = dx[jt], y = dy[jt], z = dz[jt];
           if (fresh) asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-          encode<P, KS_DIR>(x, y, z, a.multires_views, g, dir[jt]);
+          encode_auto<P, KS_DIR, kMaxMultiresViews>(x, y, z, a.multires_views, g, dir[jt]);
         }
       }
     };
@@ -298,6 +359,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     keep_masks();
     stage8(I0{}, IH{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], bias_off_stage(6), pre_of(5, &hB[0][0]), 6);
     keep_masks();
+    if (staged && wg + gridDim.x < n_wg) prefetch_inputs(wg + gridDim.x);   // the next pass's inputs: a third of a pass ahead
     stage8(I0{}, IH{}, IH{}, IH{}, &hA[0][0], &hA[0][0], &hB[0][0], bias_off_stage(7), pre_of(6, &hA[0][0]), 7);
     keep_masks();   // masks of stage 7
     Frag* cur = &hB[0][0];   // h7
@@ -573,10 +635,12 @@ template <int P, bool VD, bool TRAIN>
 static int launch_fwd(const FwdArgs& a, hipStream_t s) {
   constexpr int per_wg = ChainCfg<P, TRAIN>::WAVES * ChainCfg<P, TRAIN>::NJ;
   const int64_t n_wg = (padded_tiles<P>(a.n_samples) + per_wg - 1) / per_wg;
-  const int lds = kBiasLdsBytes + kRingBytes;
+  const int lds = kBiasLdsBytes + kRingBytes + per_wg * 5 * 256;   // bias block | weight ring | the waves' input staging areas
   if (int e = ensure_dynamic_lds<&mlp_fwd_kernel<P, VD, TRAIN>>(lds)) return e;
-  const int64_t cap = tunables().chain_grid > 0 ? tunables().chain_grid : 1024;
-  const int64_t grid = n_wg < cap ? n_wg : cap;  // one workgroup per CU is resident; the rest grid-stride
+  // one workgroup per CU is resident; since the inputs of a pass are fetched a pass ahead (round 5) the grid is persistent:
+  // a workgroup that loops keeps its bias block and its weight ring and finds its next inputs in LDS
+  const int64_t cap = tunables().chain_grid > 0 ? tunables().chain_grid : (SNR_IN_PREFETCH ? cu_count() : 1024);
+  const int64_t grid = n_wg < cap ? n_wg : cap;
   {
     ProfScope ps(K_MLP_FWD, s);
     mlp_fwd_kernel<P, VD, TRAIN><<<dim3((unsigned)grid), dim3(64 * ChainCfg<P, TRAIN>::WAVES), lds, s>>>(a);
