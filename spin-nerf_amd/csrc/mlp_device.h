@@ -83,6 +83,7 @@ template <int P, int WAVES_> struct Pipe {
   uint32_t cur_base;  // ... of the slot being consumed
 #ifdef SNR_TIMING
   unsigned long long t_wait = 0, t_bar = 0, n_acq = 0, t_start = 0;
+  unsigned long long t_phase[3] = {0, 0, 0};   // (round 5) forward: pass prologue, the skip layer's encoding, the view-direction encoding
 #endif
   int pend;          // DMA pieces of the block being issued that are still to be issued
   bool dma_on = true; // (SNR_ABLATE & 64)
@@ -171,6 +172,7 @@ template <int P, int WAVES_> struct Pipe {
     if (lane == 0) {
       atomicAdd(&g_snr_dbg[0], t_wait); atomicAdd(&g_snr_dbg[1], t_bar); atomicAdd(&g_snr_dbg[3], n_acq);
       atomicAdd(&g_snr_dbg[4], SNR_T() - t_start); atomicAdd(&g_snr_dbg[5], 1ull);
+      atomicAdd(&g_snr_dbg[2], t_phase[0]); atomicAdd(&g_snr_dbg[6], t_phase[1]); atomicAdd(&g_snr_dbg[7], t_phase[2]);
     }
 #endif
   }

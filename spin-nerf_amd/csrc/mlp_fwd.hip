@@ -165,6 +165,9 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
 
   for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
     const int64_t tile0 = (wg * WAVES + wave) * NJ;   // this wave's first 32-sample tile
+#ifdef SNR_TIMING
+    const unsigned long long tp0 = SNR_T();
+#endif
     int64_t m[NJ];
     bool valid[NJ];
     float px[NJ], py[NJ], pz[NJ], dx[NJ], dy[NJ], dz[NJ];
@@ -324,6 +327,9 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
           pre);
     };
 
+#ifdef SNR_TIMING
+    pipe.t_phase[0] += SNR_T() - tp0;
+#endif
     // stage 0: PE -> hA
     stage8(IPE{}, I0{}, IPE{}, IPE{}, &pe[0][0], &pe[0][0], &hA[0][0], bias_off_stage(0), [&](int nt) {
       if constexpr (TRAIN) {
@@ -354,7 +360,13 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
       stage8(I0{}, IH{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], bias_off_stage(s1 + 1), pre_of(s1, &hB[0][0]), s1 + 1);
     }
     keep_masks();
+#ifdef SNR_TIMING
+    const unsigned long long tp1 = SNR_T();
+#endif
     if (!kKeepEnc) make_pe(true);
+#ifdef SNR_TIMING
+    pipe.t_phase[1] += SNR_T() - tp1;
+#endif
     stage8(IPE{}, IH{}, IPE{}, IH{}, &pe[0][0], &hA[0][0], &hB[0][0], bias_off_stage(5), pre_of(4, &hA[0][0]), 5);
     keep_masks();
     stage8(I0{}, IH{}, IH{}, IH{}, &hB[0][0], &hB[0][0], &hA[0][0], bias_off_stage(6), pre_of(5, &hB[0][0]), 6);
@@ -383,7 +395,13 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
       Frag* feat = nxt;
       Frag* h9 = cur;
       clear_masks();
+#ifdef SNR_TIMING
+      const unsigned long long tp2 = SNR_T();
+#endif
       if (!kKeepEnc) make_dir(true);
+#ifdef SNR_TIMING
+      pipe.t_phase[2] += SNR_T() - tp2;
+#endif
       pipe.template run_tiles<KS_H, KS_DIR, 4, NJ, KS_H, KS_DIRA>(
           feat, &dir[0][0], [&](int nt) { return bias_tile_addr(bias_lds, kBiasViews + 32 * nt, g); },
           [&](int nt, int jt, f32x16 acc) {

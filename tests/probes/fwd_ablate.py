@@ -27,4 +27,5 @@ for name, a in (("inference", None), ("train", act)):
         buf = (ctypes.c_ulonglong * 8)()
         lib.snr_debug_read_fwd(buf)
         tw, tb, ti, na, tk, nw = [buf[i] for i in range(6)]
+        print(f"    per wave: pass prologue {buf[2]/nw:.0f} cyc, skip-layer encoding {buf[6]/nw:.0f}, view-direction encoding {buf[7]/nw:.0f}  (of kernel {tk/nw:.0f}; {M/256/ (nw/8):.1f} passes per workgroup)")
         print(f"    per wave: kernel {tk/nw:.0f} cyc, acquires {na/nw:.0f}, wait {tw/nw:.0f} ({tw/na:.0f}/acq), barrier {tb/nw:.0f} ({tb/na:.0f}/acq), issue {ti/nw:.0f} ({ti/na:.0f}/acq)  [s_memtime ticks]")
