@@ -326,7 +326,9 @@ __device__ __forceinline__ int term_of(const LossSpec& sp, int64_t ray) {
 }
 // kind 0 / 1: mean((rgb - target)^2) (1: through detached weights, helpers:385); kind 2: mean((disp - target)^2)
 __device__ __forceinline__ RayLoss ray_loss(const LossSpec& sp, int64_t ray, float r, float g, float b, float disp) {
-  RayLoss L{term_of(sp, ray), 0.f, 0.f, 0.f, 0.f, 0, 0.f};
+  // (the ray, and with it the term, is the same in every lane of the wave: as a scalar the index selects the term's fields
+  //  with scalar loads from the kernel arguments — indexed per lane the struct went to scratch memory)
+  RayLoss L{__builtin_amdgcn_readfirstlane(term_of(sp, ray)), 0.f, 0.f, 0.f, 0.f, 0, 0.f};
   if (L.term < 0) return L;
   const LossTerm& t = sp.t[L.term];
   const int64_t rel = ray - t.first;
@@ -348,15 +350,20 @@ __device__ __forceinline__ void add_losses(const LossSpec& sp, int final_pass, f
   if (lane == 0) { sq[wv] = err; st[wv] = term; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
-    bool has[4] = {false, false, false, false};
-    for (int w = 0; w < kRaysPerBlock; ++w)
-      if (st[w] >= 0) { t[st[w]] += sq[w]; has[st[w]] = true; }
-    for (int k = 0; k < 4; ++k)
-      if (has[k]) {
-        atomicAdd(loss + sp.t[k].slot, t[k]);
-        if (final_pass && sp.t[k].slot_final >= 0) atomicAdd(loss + sp.t[k].slot_final, t[k]);
+    // (no array indexed by a run-time term: that was a serial chain of scratch-memory read-modify-writes at the tail of every
+    //  workgroup; the sums run over the waves in the same order as before)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float tk = 0.f;
+      bool has = false;
+#pragma unroll
+      for (int w = 0; w < kRaysPerBlock; ++w)
+        if (st[w] == k) { tk += sq[w]; has = true; }
+      if (has) {
+        atomicAdd(loss + sp.t[k].slot, tk);
+        if (final_pass && sp.t[k].slot_final >= 0) atomicAdd(loss + sp.t[k].slot_final, tk);
       }
+    }
   }
 }
 
