@@ -298,6 +298,36 @@ def test_chunk_size_does_not_change_results(S):
         assert torch.equal(a[4][k], b[4][k]), k
 
 
+def test_deterministic_no_grad_render_is_one_minibatch_with_the_same_maps(S, monkeypatch):
+    """render.py: batchify_rays raises the minibatch of a test-time render (perturb = 0, raw_noise_std = 0, no grad) to
+    SNR_MIN_CHUNK rays: the maps are bit-identical to the chunk-by-chunk render, and the render is one pass."""
+    import importlib
+    R = importlib.import_module("spin-nerf_amd.render")
+    g = load("render_lindisp_fine_vd")
+    net_c, net_f, kw = build(S, g)
+    kw = dict(kw, perturb=0., raw_noise_std=0.)
+    H, W, f = int(g["H"]), int(g["W"]), float(g["focal"])
+    calls = []
+    real = R.render_rays
+    monkeypatch.setattr(R, "render_rays", lambda rays, **k: (calls.append(rays.shape[0]), real(rays, **k))[1])
+    with torch.no_grad():
+        monkeypatch.setenv("SNR_MIN_CHUNK", "1")
+        a = S.render(H, W, f, chunk=7, rays=T(g["rays"]).cuda(), retraw=True, **kw)
+        n_small = len(calls)
+        monkeypatch.delenv("SNR_MIN_CHUNK")
+        b = S.render(H, W, f, chunk=7, rays=T(g["rays"]).cuda(), retraw=True, **kw)
+    assert n_small > 1 and len(calls) == n_small + 1
+    same = lambda x, y: torch.equal(x.contiguous().view(torch.int32), y.contiguous().view(torch.int32))   # (bit patterns: disp of a ray that hits nothing is NaN)
+    for x, y in zip(a[:4], b[:4]):
+        assert same(x, y)
+    for k in a[4]:
+        assert same(a[4][k], b[4][k]), k
+    # with gradients enabled the caller's chunk stands
+    calls.clear()
+    S.render(H, W, f, chunk=7, rays=T(g["rays"]).cuda(), **kw)
+    assert len(calls) == n_small
+
+
 def test_need_alpha_without_fine_raises_like_reference(S):
     g = load("render_ndc_coarse_vd")
     net_c, net_f, kw = build(S, g)
