@@ -589,6 +589,47 @@ __device__ __forceinline__ void sample_fine_ray(const float* __restrict__ zc, co
   if (lane == 0 && z_std) z_std[ray] = sqrtf(var / (float)Nf);
 
   if (direct) return;
+  if (npow2 == 256) {
+    // (round 5) the standard union (64 + 128 -> 256 slots) is sorted in REGISTERS: four consecutive elements per lane, partners
+    // at distance 1 / 2 inside the lane, further ones through a lane shuffle — the same compare-exchange network as the LDS loop
+    // below (same values out), without its 36 rounds of LDS reads, writes and wave barriers
+    f32x4 r;   // (the sort buffer starts 2 (Nc - 1) floats into the wave's LDS: not 16-byte aligned)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = srt[4 * lane + c];
+    auto cx = [](float own, float other, bool lower, bool up) {   // this element after a compare-exchange with its partner
+      const float a = lower ? own : other, b = lower ? other : own;   // a: the pair's lower index
+      const bool gt = a > b;
+      return lower ? (up ? (gt ? b : a) : (gt ? a : b)) : (up ? (gt ? a : b) : (gt ? b : a));
+    };
+#pragma unroll
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+      for (int jj = k >> 1; jj > 0; jj >>= 1) {
+        if (jj >= 4) {
+          const bool lower = (lane & (jj >> 2)) == 0;
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = __shfl_xor(r[c], jj >> 2, kWave);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) r[c] = cx(r[c], o[c], lower, ((4 * lane + c) & k) == 0);
+        } else {
+          f32x4 n;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) n[c] = cx(r[c], r[c ^ jj], (c & jj) == 0, ((4 * lane + c) & k) == 0);
+          r = n;
+        }
+      }
+    }
+    const int n_out = Nc + Nf;
+    float* zo = z_out + ray * n_out;
+    if ((n_out & 3) == 0) {
+      if (4 * lane < n_out) *(f32x4*)(zo + 4 * lane) = r;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (4 * lane + c < n_out) zo[4 * lane + c] = r[c];
+    }
+    return;
+  }
   // bitonic sort of srt[0..npow2) ascending (values only, run_nerf.py:702)
   for (int k = 2; k <= npow2; k <<= 1) {
     for (int jj = k >> 1; jj > 0; jj >>= 1) {
