@@ -324,20 +324,31 @@ __device__ __forceinline__ int term_of(const LossSpec& sp, int64_t ray) {
     if (k < sp.n && ray >= sp.t[k].first && ray < sp.t[k].first + sp.t[k].n) ti = k;
   return ti;
 }
-// kind 0 / 1: mean((rgb - target)^2) (1: through detached weights, helpers:385); kind 2: mean((disp - target)^2)
-__device__ __forceinline__ RayLoss ray_loss(const LossSpec& sp, int64_t ray, float r, float g, float b, float disp) {
+// the ray's term and its target row, fetched at the TOP of a kernel: the loss needs them only behind the whole compositing
+// forward, and a dependent global load there is a microsecond nothing else covers (one wave per ray, one wave per SIMD)
+struct RayTarget { int term; float t0, t1, t2; };
+__device__ __forceinline__ RayTarget ray_target(const LossSpec& sp, int64_t ray) {
   // (the ray, and with it the term, is the same in every lane of the wave: as a scalar the index selects the term's fields
   //  with scalar loads from the kernel arguments — indexed per lane the struct went to scratch memory)
-  RayLoss L{__builtin_amdgcn_readfirstlane(term_of(sp, ray)), 0.f, 0.f, 0.f, 0.f, 0, 0.f};
+  RayTarget T{__builtin_amdgcn_readfirstlane(term_of(sp, ray)), 0.f, 0.f, 0.f};
+  if (T.term < 0) return T;
+  const LossTerm& t = sp.t[T.term];
+  const int64_t rel = ray - t.first;
+  if (t.kind == 2) T.t0 = t.target[rel];
+  else { T.t0 = t.target[3 * rel]; T.t1 = t.target[3 * rel + 1]; T.t2 = t.target[3 * rel + 2]; }
+  return T;
+}
+// kind 0 / 1: mean((rgb - target)^2) (1: through detached weights, helpers:385); kind 2: mean((disp - target)^2)
+__device__ __forceinline__ RayLoss ray_loss(const LossSpec& sp, const RayTarget& T, float r, float g, float b, float disp) {
+  RayLoss L{T.term, 0.f, 0.f, 0.f, 0.f, 0, 0.f};
   if (L.term < 0) return L;
   const LossTerm& t = sp.t[L.term];
-  const int64_t rel = ray - t.first;
   if (t.kind == 2) {
-    const float dd = disp - t.target[rel];
+    const float dd = disp - T.t0;
     L.err = dd * dd * t.inv_count;
     L.gP = 2.f * dd * t.inv_count;
   } else {
-    const float dr = r - t.target[3 * rel], dg = g - t.target[3 * rel + 1], db = b - t.target[3 * rel + 2];
+    const float dr = r - T.t0, dg = g - T.t1, db = b - T.t2;
     L.err = (dr * dr + dg * dg + db * db) * t.inv_count;
     L.gr = 2.f * dr * t.inv_count; L.gg = 2.f * dg * t.inv_count; L.gb = 2.f * db * t.inv_count;
     L.detach = t.kind == 1;
@@ -381,12 +392,13 @@ __global__ __launch_bounds__(256) void composite_train_kernel(
   if (ray < n_rays) {
     const float* rd = rays + ray * ld + 3;
     const float dn = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
+    const RayTarget tgt = ray_target(spec, ray);
     const CompMaps m = composite_fwd_ray(raw, C, z_vals + ray * S, dn, ns, ray, S, white, lane, weights, nullptr);
     if (lane == 0) {
       rgb_map[3 * ray] = m.r; rgb_map[3 * ray + 1] = m.g; rgb_map[3 * ray + 2] = m.b;
       disp_map[ray] = m.disp; acc_map[ray] = m.acc; depth_map[ray] = m.depth;
     }
-    const RayLoss L = ray_loss(spec, ray, m.r, m.g, m.b, m.disp);
+    const RayLoss L = ray_loss(spec, tgt, m.r, m.g, m.b, m.disp);
     err = L.err; term = L.term;
     composite_bwd_ray(raw, C, z_vals + ray * S, dn, ns, ray, S, white, L.detach, L.gr, L.gg, L.gb, 0.f, 0.f, L.gP, nullptr, nullptr,
                       d_raw, lane);
@@ -411,6 +423,7 @@ __device__ __forceinline__ float composite_train_ray(
   {
     const float* rd = rays + ray * ld + 3;
     const float* zr = z_vals + ray * S;
+    const RayTarget tgt = ray_target(spec, ray);   // (with the ray's other loads)
     float z[NCH], zn[NCH], r0[NCH], r1[NCH], r2[NCH], s[NCH];
     bool in[NCH];
 #pragma unroll
@@ -465,7 +478,7 @@ __device__ __forceinline__ float composite_train_ray(
       disp_map[ray] = disp; acc_map[ray] = sa; depth_map[ray] = sd;
     }
     // ---- loss gradient and backward (composite_bwd_ray with g_acc = g_depth = 0) ----
-    const RayLoss L = ray_loss(spec, ray, sr, sg, sb, disp);
+    const RayLoss L = ray_loss(spec, tgt, sr, sg, sb, disp);
     term = L.term;
     e2 = L.err;
     const float gr = L.gr, gg = L.gg, gb = L.gb;
