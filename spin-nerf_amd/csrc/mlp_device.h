@@ -565,13 +565,14 @@ __device__ __forceinline__ void encode_static(float x, float y, float z, int g, 
   });
 }
 // bf16 with the reference's frequency counts takes the static version (a wave-uniform branch); everything else the generic one
+// (Lsel: L, or -1 to force the generic version — SNR_ENC_GENERIC, the bit-identity test)
 template <int P, int KS, int LT>
-__device__ __forceinline__ void encode_auto(float x, float y, float z, int L, int g, typename Mma<P>::Frag* out) {
+__device__ __forceinline__ void encode_auto(float x, float y, float z, int Lsel, int L, int g, typename Mma<P>::Frag* out) {
 #ifndef SNR_ENC_STATIC
 #define SNR_ENC_STATIC 1   // A/B builds: 0 = the generic encoding everywhere
 #endif
   if constexpr (P == kBF16 && SNR_ENC_STATIC) {
-    if (L == LT) { encode_static<P, KS, LT>(x, y, z, g, out); return; }
+    if (Lsel == LT) { encode_static<P, KS, LT>(x, y, z, g, out); return; }
   }
   encode<P, KS>(x, y, z, L, g, out);
 }

@@ -97,6 +97,7 @@ struct FwdArgs {
   float* raw;
   char* act;               // null = inference
   int save_even;           // 0: h0, h2, h4, h6 are not saved (the weight-gradient pass rebuilds them, mlp_wgrad_pair.h)
+  int enc_generic;         // 1: the run-time encoding everywhere (SNR_ENC_GENERIC: the bit-identity test of encode_static)
 };
 
 template <int P, bool VD, bool TRAIN>
@@ -232,7 +233,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
       for (int jt = 0; jt < NJ; ++jt) {
         float x = px[jt], y = py[jt], z = pz[jt];
         if (fresh) asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-        encode_auto<P, KS_PE, kMaxMultires>(x, y, z, a.multires, g, pe[jt]);
+        encode_auto<P, KS_PE, kMaxMultires>(x, y, z, a.enc_generic ? -1 : a.multires, a.multires, g, pe[jt]);
       }
     };
     auto make_dir = [&](bool fresh) {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
         for (int jt = 0; jt < NJ; ++jt) {
           float x = dx[jt], y = dy[jt], z = dz[jt];
           if (fresh) asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-          encode_auto<P, KS_DIR, kMaxMultiresViews>(x, y, z, a.multires_views, g, dir[jt]);
+          encode_auto<P, KS_DIR, kMaxMultiresViews>(x, y, z, a.enc_generic ? -1 : a.multires_views, a.multires_views, g, dir[jt]);
         }
       }
     };
@@ -703,6 +704,7 @@ extern "C" int snr_mlp_forward(const snr_mlp_config* c, const void* packed, cons
   a.multires = T.multires; a.multires_views = T.multires_views; a.out_ch = c->out_ch;
   a.raw = raw; a.act = (char*)act;
   a.save_even = !(bf && recompute_enabled());
+  a.enc_generic = tunables().enc_generic;
   hipStream_t s = (hipStream_t)stream;
   const bool vd = c->use_viewdirs, tr = act != nullptr;
   if (bf && vd && !tr && tunables().chain2 && T.fwd_frags == c2::FwdMap::kBlocks * c2::kBF) return launch_fwd2<false>(a, s);

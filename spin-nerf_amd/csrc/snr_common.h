@@ -63,6 +63,7 @@ struct Tunables {
   int only_kind, only_pair;  // SNR_PAIR_KIND / SNR_PAIR_PAIR (debug builds of the pair kernel only)
   int merge_nets;            // SNR_MERGE_NETS=0: one backward launch sequence per network (A/B against the merged one)
   int chain_grid;            // SNR_CHAIN_GRID: workgroups of a chain-kernel launch (the rest grid-stride); 0 = default
+  int enc_generic;           // SNR_ENC_GENERIC=1: the forward kernel's run-time positional encoding even where the compile-time one applies (tests)
   int chain2;                // SNR_CHAIN2: the bf16 chain kernels with helper waves (mlp_chain2.h); 0 = the round-2 kernels (A/B)
 };
 inline Tunables read_tunables() {
@@ -80,6 +81,7 @@ inline Tunables read_tunables() {
   t.only_pair = geti("SNR_PAIR_PAIR", -1);
   t.merge_nets = geti("SNR_MERGE_NETS", 1);
   t.chain2 = geti("SNR_CHAIN2", 0);
+  t.enc_generic = geti("SNR_ENC_GENERIC", 0);
   t.chain_grid = geti("SNR_CHAIN_GRID", 0);
   return t;
 }

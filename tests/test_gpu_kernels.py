@@ -96,6 +96,42 @@ def test_mlp_forward_many_tiles_and_ray_form(S):
     close(out, ref, atol=5e-5, rtol=5e-5)
 
 
+@pytest.mark.parametrize("vd", [True, False])
+def test_compile_time_encoding_is_bit_identical_to_the_run_time_one(S, vd, monkeypatch):
+    """mlp_device.h: encode_static (round 5) replaces the run-time positional encoding where multires = 10 /
+    multires_views = 4; its scale 2^k / 2 pi is ONE multiplication, which rounds to the same float (scaling by a power of
+    two is exact).  SNR_ENC_GENERIC=1 forces the run-time version: raw and EVERY byte of the saved-activation workspace
+    (the encodings are its first sections) must agree, inference and training mode, ragged sizes."""
+    L = S._lib
+    lib = L.load()
+    net = S.NeRF(input_ch=63, input_ch_views=27 if vd else 0, use_viewdirs=vd, precision="bf16").cuda()
+    packed = net.packed_weights()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    try:
+        for n_rays, Sps in ((1, 1), (37, 7), (300, 192)):
+            M = n_rays * Sps
+            rays = torch.randn(n_rays, 8, device="cuda", generator=g) * 2.0
+            z = torch.sort(torch.rand(n_rays, Sps, device="cuda", generator=g) * 6 + 1, dim=-1).values.contiguous()
+            vdirs = torch.nn.functional.normalize(torch.randn(n_rays, 3, device="cuda", generator=g), dim=-1).contiguous()
+            outs = []
+            for generic in ("0", "1"):
+                monkeypatch.setenv("SNR_ENC_GENERIC", generic)
+                lib.snr_tunables_reload()
+                for train in (False, True):
+                    raw = torch.zeros(M, 4, device="cuda")
+                    act = torch.zeros(lib.snr_mlp_act_bytes(net.cfg, M), dtype=torch.uint8, device="cuda") if train else None
+                    L.check(lib.snr_mlp_forward(net.cfg, L.ptr(packed), None, L.ptr(rays), 8, L.ptr(z), L.ptr(vdirs) if vd else None, 3,
+                                                M, Sps, L.ptr(raw), L.ptr(act), L.stream()), "snr_mlp_forward")
+                    outs.append((raw, act))
+            for (r0, a0), (r1, a1) in zip(outs[:2], outs[2:]):
+                assert torch.equal(r0.view(torch.int32), r1.view(torch.int32))
+                assert (a0 is None) == (a1 is None) and (a0 is None or torch.equal(a0, a1))
+            assert float(outs[0][0].abs().max()) > 0
+    finally:
+        monkeypatch.delenv("SNR_ENC_GENERIC", raising=False)
+        lib.snr_tunables_reload()
+
+
 # ---------------------------------------------------------------------------------------------
 # raw2outputs
 # ---------------------------------------------------------------------------------------------
