@@ -135,7 +135,9 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     for (int jt = 0; jt < NJ; ++jt) {
       int64_t mt = ((wgn * WAVES + wave) * NJ + jt) * 32 + sj;
       if (mt >= a.n_samples) mt = a.n_samples - 1;   // (a tile's tail beyond n_samples is masked by `valid`: any readable sample)
-      const int64_t ray = small_n ? (int64_t)((uint32_t)mt / (uint32_t)a.S) : mt / a.S;
+      uint32_t s32 = (uint32_t)a.S;
+      asm volatile("" : "+s"(s32));
+      const int64_t ray = small_n ? (int64_t)((uint32_t)mt / s32) : mt / a.S;
       const float* pr = a.rays + ray * a.ray_ld;
       const float* pv = VD ? a.viewdirs + ray * a.vd_ld : pr;
       const float* src[5] = {g ? pr : a.z_vals + mt, pr + 1 + g, pr + 3 + g, g ? pv : pr + 5, pv + 1 + g};
@@ -198,8 +200,12 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
         }
         continue;
       }
-      // (the ray of a sample: a 32-bit division where the launch allows it)
-      const int64_t ray = !valid[jt] ? 0 : (small_n ? (int64_t)((uint32_t)m[jt] / (uint32_t)a.S) : m[jt] / a.S);
+      // (the ray of a sample: a 32-bit division where the launch allows it.  The divisor is an opaque copy: hoisted out of the
+      //  pass loop, the division's reciprocal constant was spilled to scratch memory and re-loaded behind a vmcnt(0) at the top
+      //  of every pass)
+      uint32_t s32 = (uint32_t)a.S;
+      asm volatile("" : "+s"(s32));
+      const int64_t ray = !valid[jt] ? 0 : (small_n ? (int64_t)((uint32_t)m[jt] / s32) : m[jt] / a.S);
       if (valid[jt]) {
 #if SNR_ABLATE & 256   // timing experiment (round 5): no global loads in the pass prologue (positions from the sample index)
         px[jt] = 1e-6f * (float)(int)m[jt]; py[jt] = 0.5f * px[jt]; pz[jt] = 1.f - px[jt];

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where do a kernel's register spills execute?  tools/check_spills.py file.gfx950.s [kernel-name-substring ...]
+"""Where do a kernel's register spills execute?  tools/check_spills.py file.gfx950.s [kernel-name-substring ...] [--no-scratch name ...]
 
 For every kernel of the listing that has spills (scratch_load / scratch_store = VGPR spills, v_writelane_b32 / v_readlane_b32 with
 the compiler's "SGPR spill" comment = SGPR spills to VGPR lanes) this prints how many of those instructions sit inside a LOOP
@@ -52,7 +52,12 @@ def analyse(body):
 
 def main():
     txt = open(sys.argv[1]).read()
-    want = sys.argv[2:]
+    args = sys.argv[2:]
+    # kernels named behind --no-scratch must not touch scratch memory AT ALL: in the chain kernels a scratch load sits behind a
+    # vmcnt(0), which also drains the weight stream's LDS-DMA queue (round 5: a hoisted division constant did exactly that at the
+    # top of every pass of the forward kernel)
+    no_scratch = args[args.index("--no-scratch") + 1:] if "--no-scratch" in args else []
+    want = args[:args.index("--no-scratch")] if "--no-scratch" in args else args
     bad = 0
     for name, body in kernels(txt):
         n_hot, vg, sg, vg_hot, sg_hot, lines, hot = analyse(body)
@@ -66,6 +71,9 @@ def main():
         s_in = [x for x in sg_hot if any(a <= x[0] <= b for a, b in innermost)]
         print(f"{name[:60]:60s} MFMA loops {n_hot:2d} (innermost {len(innermost)})  VGPR spill ops {vg:3d} (in an innermost MFMA loop: {len(v_in)})  "
               f"SGPR spill ops {sg:3d} (in an innermost MFMA loop: {len(s_in)})")
+        if vg and any(w in name for w in no_scratch):
+            bad += 1
+            print("    scratch memory in a kernel that must not use it")
         if want and any(w in name for w in want) and (v_in or s_in):
             bad += 1
             for i, l, span in (v_in + s_in)[:10]:
