@@ -211,6 +211,11 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
         px[jt] = 1e-6f * (float)(int)m[jt]; py[jt] = 0.5f * px[jt]; pz[jt] = 1.f - px[jt];
         if constexpr (VD) { dx[jt] = px[jt]; dy[jt] = py[jt]; dz[jt] = pz[jt]; }
 #else
+        // (the view direction first: its load goes out with the ray's, not behind the wait for them — one round trip per pass)
+        if constexpr (VD) {
+          const float* v = a.viewdirs + ray * a.vd_ld;
+          dx[jt] = v[0]; dy[jt] = v[1]; dz[jt] = v[2];
+        }
         if (a.pts) {
           px[jt] = a.pts[3 * m[jt]]; py[jt] = a.pts[3 * m[jt] + 1]; pz[jt] = a.pts[3 * m[jt] + 2];
         } else {
@@ -220,10 +225,6 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
           px[jt] = mul_add_unfused(r[3], t, r[0]);
           py[jt] = mul_add_unfused(r[4], t, r[1]);
           pz[jt] = mul_add_unfused(r[5], t, r[2]);
-        }
-        if constexpr (VD) {
-          const float* v = a.viewdirs + ray * a.vd_ld;
-          dx[jt] = v[0]; dy[jt] = v[1]; dz[jt] = v[2];
         }
 #endif
       }
