@@ -200,7 +200,8 @@ int snr_sample_fine_rng(const float* z_coarse, const float* weights, int64_t n_r
  * elements, so that data-parallel shards sum to the global mean) + the backward of both, in one kernel: maps and weights
  * as snr_composite_forward, d_raw as snr_composite_backward would give for g_rgb = d loss / d rgb_map.  Density noise:
  * `noise` [n_rays,S] pre-scaled, or NULL with noise_std > 0 = N(0,1) * noise_std drawn in-kernel (the same numbers in the
- * forward and the backward half).  loss[0] += the term, and loss_also[0] too when non-NULL (zero them first). */
+ * forward and the backward half).  loss[0] += the term, and loss_also[0] too when non-NULL (zero them first); the two are
+ * independent accumulators: any two 4-byte aligned device floats, not necessarily of one allocation. */
 int snr_composite_train(const float* raw, int raw_ch, const float* z_vals, const float* rays, int ray_ld,
                         const float* noise, float noise_std, uint64_t seed, uint64_t offset, int64_t n_rays, int S,
                         int white_bkgd, int detach_weights, const float* target, int64_t n_rays_global, float* rgb_map,

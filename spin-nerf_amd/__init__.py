@@ -6,6 +6,7 @@ The directory name carries a hyphen (it mirrors the reference repo's name), so i
     import spin_nerf_amd                      # alias module at the repo root
     importlib.import_module("spin-nerf_amd")  # the package itself
 """
+from . import _debug          # SNR_POISON_WS=1: poison-filled torch.empty (debug)
 from . import _lib
 from ._lib import HipLibraryError, LIB_PATH
 from .nerf import NeRF, NeRF_RGB

@@ -120,7 +120,7 @@ int forward_impl(const snr_render_config* cfg, const snr_net* coarse, const snr_
           t.slot_final > 3 || t.kind < SNR_LOSS_RGB || t.kind > SNR_LOSS_DISP)
         return SNR_ERR_SHAPE;
       const float inv = t.kind == SNR_LOSS_DISP ? 1.f / (float)t.count : 1.f / (3.f * (float)t.count);
-      spec.t[k] = snr::LossTerm{t.first_ray, t.n_rays, t.kind, t.target, inv, t.slot, t.slot_final < 0 ? -1 : t.slot_final};
+      spec.t[k] = snr::LossTerm{t.first_ray, t.n_rays, t.kind, t.target, inv, t.slot, t.slot_final < 0 ? snr::kNoSlot : (int64_t)t.slot_final};
     }
     if (terms->guard_term >= 0 && terms->term[terms->guard_term].slot == 0) return SNR_ERR_SHAPE;
   }
@@ -151,7 +151,7 @@ int forward_impl(const snr_render_config* cfg, const snr_net* coarse, const snr_
   bool sampled = false;   // the hierarchical sampling ran inside the compositing launch
   if (train && !last0) {
     // compositing + loss + its backward of the coarse samples AND hierarchical sampling + sort from the weights, one kernel.
-    // It declines shapes it does not cover (SNR_ERR_UNSUPPORTED: Nc > 64, unaligned raw rows): only then the two-kernel route
+    // It declines shapes it does not cover (SNR_ERR_UNSUPPORTED: Nc > 64 or Nc < 3, unaligned raw rows, a sample union beyond its LDS): only then the two-kernel route
     // below takes over — any other status is a real error and is returned
     st = snr::composite_train_sample_impl(F(L.raw0), C0, F(L.z_coarse), rays, ray_ld, noise0, cfg->raw_noise_std, seed, offset + 2,
                                           offset_base, n_rays, Nc, cfg->white_bkgd, spec, m_rgb, m_disp, m_acc,

@@ -12,7 +12,10 @@ int sample_fine_rng_impl(const float* z_coarse, const float* weights, int64_t n_
                          uint64_t offset, const uint64_t* base, float* z_out, float* z_samples, float* z_std,
                          snr_stream_t stream);
 // the loss terms of a training render (include/spinnerf_hip.h: snr_loss_terms), as the kernels take them: by value
-struct LossTerm { int64_t first, n; int kind; const float* target; float inv_count; int slot, slot_final; };
+// slot / slot_final are ELEMENT offsets from the kernels' `loss` pointer: 0..3 for the library routes (one 4-float block); the
+// public snr_composite_train passes the distance to its independent second accumulator in slot_final (any sign): kNoSlot = none
+constexpr int64_t kNoSlot = INT64_MIN;
+struct LossTerm { int64_t first, n; int kind; const float* target; float inv_count; int slot; int64_t slot_final; };
 struct LossSpec { int n; LossTerm t[4]; };
 // one term over rays [0, n_rays): mean((rgb - target)^2) over 3 * n_rays_global elements into loss[0] (and loss[1] from the final pass)
 inline LossSpec plain_rgb_loss(const float* target, int64_t n_rays, int64_t n_rays_global) {

@@ -372,7 +372,7 @@ __device__ __forceinline__ void add_losses(const LossSpec& sp, int final_pass, f
         if (st[w] == k) { tk += sq[w]; has = true; }
       if (has) {
         atomicAdd(loss + sp.t[k].slot, tk);
-        if (final_pass && sp.t[k].slot_final >= 0) atomicAdd(loss + sp.t[k].slot_final, tk);
+        if (final_pass && sp.t[k].slot_final != kNoSlot) atomicAdd(loss + sp.t[k].slot_final, tk);
       }
     }
   }
@@ -1165,7 +1165,10 @@ int snr::composite_train_sample_impl(const float* raw, int C, const float* z, co
                                      float* z_std, snr_stream_t stream) {
   SNR_CHECK_ARG(raw && z && rays && rgb_map && disp_map && acc_map && depth_map && weights && d_raw && loss && z_out,
                 SNR_ERR_NULL);
-  SNR_CHECK_ARG(n_rays > 0 && Nc >= 3 && Nc <= kWave && Nf >= 1 && C >= 4 && ld >= 6 && spec.n >= 0 && spec.n <= 4, SNR_ERR_SHAPE);
+  // coverage limits first (the caller's two-kernel route takes these: ADVICE r05): one wave holds a ray's coarse samples, and the
+  // register sort needs an interior bin
+  if (Nc > kWave || Nc < 3) return SNR_ERR_UNSUPPORTED;
+  SNR_CHECK_ARG(n_rays > 0 && Nf >= 1 && C >= 4 && ld >= 6 && spec.n >= 0 && spec.n <= 4, SNR_ERR_SHAPE);
   for (int k = 0; k < spec.n; ++k) SNR_CHECK_ARG(spec.t[k].target, SNR_ERR_NULL);
   if (C == 4 && ((((uintptr_t)raw) | ((uintptr_t)d_raw)) & 15) != 0) return SNR_ERR_UNSUPPORTED;
   int npow2 = 2;
@@ -1217,16 +1220,16 @@ extern "C" int snr_composite_train(const float* raw, int C, const float* z, cons
                                    float* loss, float* loss_also, snr_stream_t stream) {
   SNR_CHECK_ARG(target && loss, SNR_ERR_NULL);
   SNR_CHECK_ARG(n_rays > 0 && n_rays_global >= n_rays, SNR_ERR_SHAPE);
-  // the kernels address their accumulators as slots of one 4-float block: `loss` and `loss_also` must lie within one
-  float* base = (loss_also && loss_also < loss) ? loss_also : loss;
-  const int64_t s0 = loss - base, s1 = loss_also ? loss_also - base : -1;
-  if (s0 > 3 || s1 > 3) return SNR_ERR_UNSUPPORTED;
+  // two independent accumulators (include/spinnerf_hip.h): the kernels add a term to loss[slot] and loss[slot_final], element
+  // offsets from one pointer — here slot 0 of `loss` and the signed distance to `loss_also` (integer arithmetic on the addresses:
+  // the two need not belong to one allocation)
+  SNR_CHECK_ARG(((((uintptr_t)loss) | ((uintptr_t)loss_also)) & 3) == 0, SNR_ERR_SHAPE);
   snr::LossSpec sp = snr::plain_rgb_loss(target, n_rays, n_rays_global);
   sp.t[0].kind = detach ? 1 : 0;
-  sp.t[0].slot = (int)s0;
-  sp.t[0].slot_final = (int)s1;
+  sp.t[0].slot = 0;
+  sp.t[0].slot_final = loss_also ? ((int64_t)(intptr_t)loss_also - (int64_t)(intptr_t)loss) / 4 : snr::kNoSlot;
   return snr::composite_train_impl(raw, C, z, rays, ld, noise, noise_std, seed, offset, nullptr, n_rays, S, white, sp, 1, rgb_map,
-                                   disp_map, acc_map, depth_map, weights, d_raw, base, stream);
+                                   disp_map, acc_map, depth_map, weights, d_raw, loss, stream);
 }
 
 extern "C" int snr_make_rays(int H, int W, float focal, const float* c2w_host, int i0, int j0, int h, int w, int ndc,

@@ -533,6 +533,10 @@ def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bk
         keep = []
         for k, t in enumerate(loss_terms):
             tg = f32c(t["target"])
+            per_ray = 1 if int(t["kind"]) == _lib.LOSS_DISP else 3
+            if not tg.is_cuda or tg.device != dev or tg.numel() < per_ray * int(t["n"]):
+                raise _lib.HipLibraryError(f"loss term {k}: the target must be a tensor of {per_ray} x {int(t['n'])} elements on {dev} "
+                                           f"(got {tuple(tg.shape)} on {tg.device})")
             keep.append(tg)
             lt.term[k] = _lib.LossTerm(int(t["first"]), int(t["n"]), int(t["kind"]), tg.data_ptr(),
                                        int(t.get("count") or t["n"]), int(t["slot"]), int(t.get("slot_final", -1)))
@@ -543,6 +547,8 @@ def fused_forward(net_c, net_f, rays, N_samples, N_importance, lindisp, white_bk
             ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(rgb0), ptr(disp0), ptr(acc0), ptr(z_std), ptr(loss), stream()),
             "snr_render_rays_fused_forward_terms")
         return FusedRender(rc, (sc, sf), (pc, pf, arr), rays, n, ws, L, (rgb, disp, acc, depth, rgb0, disp0, acc0, z_std), loss)
+    if target is not None and (not target.is_cuda or target.device != dev or target.numel() < 3 * n):
+        raise _lib.HipLibraryError(f"the target must be a tensor of 3 x {n} elements on {dev} (got {tuple(target.shape)} on {target.device})")
     check(lib.snr_render_rays_fused_forward(
         ctypes.byref(rc), ctypes.byref(sc), fptr, ptr(rays), rays.shape[1], n, ptr(arr["t_rand"]), ptr(arr["u"]),
         ptr(arr["noise_c"]), ptr(arr["noise_f"]), int(seed), int(offset), ptr(offset_base), ptr(target),

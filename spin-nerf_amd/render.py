@@ -206,9 +206,23 @@ def render_rays(ray_batch,
 # ----------------------------------------------------------------------------------------------
 # batchify_rays / render (run_nerf.py:74-165)
 # ----------------------------------------------------------------------------------------------
-def _min_chunk():
+_BYTES_PER_RAY = 16 * 1024      # upper estimate of what a no-grad render keeps per ray (z, raw, weights, maps of both passes: ~6 KB
+                                 # with the 8 x 256 MLP at 64 + 128 samples; the hash-grid network's saved features add little)
+
+
+def _min_chunk(device=None):
+    """rays a deterministic no-grad render may take as ONE minibatch: SNR_MIN_CHUNK when set (tests: 1 restores the caller's chunk),
+    else 2^18 — but never more than half of the device memory that is free right now allows (`chunk` is the
+    reference's memory bound, run_nerf.py:100-101; raising it must not defeat that on a busy device)."""
     import os
-    return int(os.environ.get("SNR_MIN_CHUNK", 1 << 18))
+    env = os.environ.get("SNR_MIN_CHUNK")
+    if env:
+        return int(env)
+    n = 1 << 18
+    if device is not None and device.type == "cuda":
+        free, _ = torch.cuda.mem_get_info(device)
+        n = min(n, int(free // 2 // _BYTES_PER_RAY))
+    return n
 
 
 def batchify_rays(rays_flat, chunk=1024 * 32, need_alpha=False, detach_weights=False, **kwargs):
@@ -216,11 +230,12 @@ def batchify_rays(rays_flat, chunk=1024 * 32, need_alpha=False, detach_weights=F
 
     ``chunk`` bounds memory in the reference (24 GB cards).  A deterministic no-grad render (test time: perturb = 0,
     raw_noise_std = 0 — every full frame of render_path) keeps ~6 KB per ray here, so on a 288 GB part the minibatch is raised
-    to at least SNR_MIN_CHUNK rays (default 2^18 = 1.6 GB): a 378 x 504 frame is one pass of five launches instead of six
-    passes and their concatenations (0.5 ms of 41; the maps are bit-identical: samples and rays are independent)."""
+    to 2^18 rays (1.6 GB) where the device's free memory allows — never below the caller's chunk, and SNR_MIN_CHUNK overrides
+    the figure: a 378 x 504 frame is one pass of five launches instead of six passes and their
+    concatenations (0.5 ms of 41; the maps are bit-identical: samples and rays are independent)."""
     randoms = kwargs.pop("randoms", None)
     if not torch.is_grad_enabled() and randoms is None and not kwargs.get("perturb", 0.) and not kwargs.get("raw_noise_std", 0.):
-        chunk = max(int(chunk), _min_chunk())
+        chunk = max(int(chunk), _min_chunk(rays_flat.device))
     all_ret = {}
     for i in range(0, rays_flat.shape[0], chunk):
         rnd = None

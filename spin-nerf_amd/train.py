@@ -521,6 +521,19 @@ class RenderTrainer:
         n = a["batch_rays_clf"].shape[1] + a["batch_rays"].shape[1] + a["batch_inp"].shape[1]
         if not self._direct_ok(a["batch_rays_clf"], n, {}) or n > a.get("chunk", 1024 * 32) * 3:
             return False
+        # the library route hands raw device pointers to the kernels: every tensor must live on the rays' device and hold exactly
+        # its ray range's elements (anything else takes the general route, whose torch ops raise the usual device / shape errors)
+        dev = a["batch_rays_clf"].device
+        for rays, tgt, per_ray in ((a["batch_rays_clf"], a["target_clf"], 3), (a["batch_rays"], a["target_s"], 3),
+                                   (a["batch_inp"], a["depth_inp"], 1)):
+            if not (isinstance(tgt, torch.Tensor) and rays.is_cuda and rays.device == dev and tgt.device == dev
+                    and tgt.numel() == per_ray * rays.shape[1]):
+                return False
+        rnd = a.get("randoms")
+        if rnd:      # injected draws: for all three renders or for none (a partial list cannot be honoured by ONE concatenated render)
+            have = [r is not None for r in list(rnd)[:3]] + [False] * (3 - len(list(rnd)[:3]))
+            if any(have) and not all(have):
+                return False
         from .nerf import NeRF
         kw = self.kw
         nets = [kw.get('network_fn')] + ([kw['network_fine']] if kw.get('N_importance', 0) > 0 and kw.get('network_fine') is not None else [])

@@ -598,3 +598,28 @@ def test_composite_propagates_a_nan_density_like_torch_relu():
     for k in (0, 2):
         np.testing.assert_allclose(rgb[k].cpu().numpy(), ref[0][k].numpy(), atol=2e-6)
         assert bool(torch.isfinite(acc[k]))
+
+
+def test_composite_train_accumulators_are_independent_pointers():
+    """include/spinnerf_hip.h: snr_composite_train adds its term to loss[0] and to loss_also[0], two INDEPENDENT accumulators
+    (ABI v4 had silently required them to lie within one 4-float block).  Separately allocated scalars, far apart
+    and in either address order, receive the same term as the adjacent pair."""
+    import spin_nerf_amd as S
+    rs = np.random.RandomState(3)
+    raw = torch.from_numpy(rs.normal(size=(9, 64, 4)).astype(np.float32)).cuda()
+    z = torch.sort(torch.from_numpy(rs.uniform(2, 6, size=(9, 64)).astype(np.float32)), -1)[0].cuda()
+    rays = torch.zeros(9, 11); rays[:, 5] = -1.0; rays[:, 10] = -1.0
+    rays = rays.cuda()
+    tgt = torch.from_numpy(rs.uniform(size=(9, 3)).astype(np.float32)).cuda()
+    pair = torch.zeros(2, device="cuda")
+    ref = S.ops.composite_train(raw, z, rays, tgt, pair[0:1], pair[1:2], noise_std=0.0, seed=1, offset=1)
+    assert float(pair[0]) > 0 and float(pair[0]) == float(pair[1])
+    far = torch.zeros(1 << 22, device="cuda")          # 16 MB between the two scalars
+    for a, b in ((far[0:1], far[-1:]), (far[-1:], far[0:1]), (torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda"))):
+        a.zero_(); b.zero_()
+        out = S.ops.composite_train(raw, z, rays, tgt, a, b, noise_std=0.0, seed=1, offset=1)
+        assert abs(float(a) - float(pair[0])) < 1e-6 * float(pair[0]) and abs(float(b) - float(pair[0])) < 1e-6 * float(pair[0])
+        assert torch.equal(out[5], ref[5]) and torch.equal(out[0], ref[0])
+    # ... and only those two floats were touched
+    far[0] = 0; far[-1] = 0
+    assert float(far.abs().max()) == 0.0

@@ -373,3 +373,62 @@ def test_colmap_depth_render_and_prepare_export_and_lpips_hookup(tmp_path):
     assert sorted(os.listdir(tmp_path / "prep")) == ["img000.png", "img001.png", "label"]
     assert sorted(os.listdir(tmp_path / "prep" / "label")) == ["img000.png", "img001.png"]
     assert open(tmp_path / "prep" / "img000.png", "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+
+
+@pytest.mark.parametrize("Nc,Nf", [(96, 32), (65, 16)])
+def test_library_routes_with_coarse_sample_counts_the_fused_compositing_kernel_does_not_cover(monkeypatch, Nc, Nf):
+    """the coarse compositing + hierarchical-sampling kernel holds a ray's coarse samples in one 64-lane
+    wave (3 <= N_samples <= 64); beyond that it must DECLINE (SNR_ERR_UNSUPPORTED) so that the library route falls back to its
+    two-kernel form, not fail the step with SNR_ERR_SHAPE.  RenderTrainer.step and spin_iteration with N_samples = 96 (and 65)
+    and a fine pass (the reference itself cannot run N_samples = 2 with a fine pass: sample_pdf indexes an empty bin list): loss and parameter gradients of the library route against the render() + autograd route (itself held to
+    the oracle above), and the step's loss against the oracle's three renders."""
+    c = _spin_setup(Nc=Nc, Nf=Nf, N=24)
+    tr, (net_c, net_f), (sd_c, sd_f) = c["tr"], c["nets"], c["sd"]
+    H, W, focal = c["hwf"]
+    cu = lambda t: t.cuda()
+    rays, rnds = c["rays"], c["rnds"]
+    curnd = [{k: cu(v) for k, v in r.items()} for r in rnds]
+    args = (H, W, focal, cu(rays[0]), cu(c["t_clf"]), cu(rays[1]), cu(c["t_all"]), cu(rays[2]), cu(c["d_inp"]))
+    p0 = [n.flat.detach().clone() for n in (net_c, net_f)]
+
+    def restore():
+        for n, p in zip((net_c, net_f), p0):
+            with torch.no_grad():
+                n.flat.copy_(p)
+            n.mark_weights_changed()
+            n.flat.grad = None
+
+    # ---- the SPIn-NeRF iteration: direct route vs autograd route vs oracle ----
+    assert tr._spin_direct_ok(args, dict(randoms=curnd))
+    loss, psnr = tr.spin_iteration(*args, randoms=curnd)
+    g_direct = [n.flat.grad.clone() for n in (net_c, net_f)]
+    assert all(bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0 for g in g_direct)
+    okw = dict(sd_coarse=sd_c, sd_fine=sd_f, N_samples=Nc, N_importance=Nf, perturb=1.0, white_bkgd=False, lindisp=False,
+               use_viewdirs=True, ndc=False, near=c["near"], far=c["far"], retraw=True)
+    with torch.no_grad():
+        rgb, _, _, _, ex = O.render(H, W, focal, rays=rays[0], randoms=rnds[0], **okw)
+        rgb_c, _, _, _, ex_c = O.render(H, W, focal, rays=rays[1], randoms=rnds[1], detach_weights=True, **okw)
+        _, disp_i, _, _, ex_i = O.render(H, W, focal, rays=rays[2], randoms=rnds[2], **okw)
+        ref = (O.img2mse(rgb, c["t_clf"]) + O.img2mse(rgb_c, c["t_all"]) + O.img2mse(ex_c["rgb0"], c["t_all"])
+               + O.img2mse(ex["rgb0"], c["t_clf"]) + O.img2mse(disp_i, c["d_inp"]) + O.img2mse(ex_i["disp0"], c["d_inp"]))
+    assert abs(float(loss) - float(ref)) < 2e-4 * abs(float(ref)), (float(loss), float(ref))
+    restore()
+    monkeypatch.setenv("SNR_NO_DIRECT_SPIN", "1")
+    loss_a, psnr_a = tr.spin_iteration(*args, randoms=curnd)
+    monkeypatch.delenv("SNR_NO_DIRECT_SPIN")
+    assert abs(float(loss_a) - float(loss)) < 2e-6 * abs(float(loss)), (float(loss_a), float(loss))
+    for n, gd in zip((net_c, net_f), g_direct):
+        assert float((n.flat.grad - gd).norm() / gd.norm()) < 2e-5
+
+    # ---- the plain step: library route vs autograd route ----
+    restore()
+    l1, rgb1 = tr.step(H, W, focal, args[3], args[4], randoms=curnd[0])
+    g1 = [n.flat.grad.clone() for n in (net_c, net_f)]
+    restore()
+    monkeypatch.setenv("SNR_NO_DIRECT_STEP", "1")
+    l2, rgb2 = tr.step(H, W, focal, args[3], args[4], randoms=curnd[0])
+    monkeypatch.delenv("SNR_NO_DIRECT_STEP")
+    assert abs(float(l1) - float(l2)) < 2e-6 * abs(float(l2)), (float(l1), float(l2))
+    assert float((rgb1 - rgb2).abs().max()) < 1e-6
+    for n, gd in zip((net_c, net_f), g1):
+        assert float((n.flat.grad - gd).norm() / gd.norm()) < 2e-5

@@ -128,6 +128,12 @@ def test_spill_checker_tells_a_tile_loop_from_the_prologue(tmp_path):
     bad = tmp_path / "bad.s"; bad.write_text(head + loop % spill + tail)
     assert subprocess.run([sys.executable, tool, str(good), "kernel"]).returncode == 0
     assert subprocess.run([sys.executable, tool, str(bad), "kernel"]).returncode == 1
+    # a gate name that matches no kernel of the listings fails instead of passing on nothing; a stated budget of
+    # in-loop spill operations passes at the budget and fails below it
+    assert subprocess.run([sys.executable, tool, str(good), "renamed_kernel"]).returncode == 1
+    assert subprocess.run([sys.executable, tool, str(good), str(bad), "--no-scratch", "renamed"]).returncode == 1
+    assert subprocess.run([sys.executable, tool, str(bad), "--max-inner", "kernel=1"]).returncode == 0
+    assert subprocess.run([sys.executable, tool, str(bad), "--max-inner", "kernel=0"]).returncode == 1
     lst = os.path.join(ROOT, "spin-nerf_amd", "lib", "mlp_bwd.gfx950.s")
     if os.path.exists(lst):
         r = subprocess.run([sys.executable, tool, lst, "mlp_wgrad_pair_kernel", "mlp_wgrad_kernelILi0"], capture_output=True, text=True)
