@@ -177,6 +177,25 @@ class NeRF(nn.Module):
         self._packed_key = None
         return self
 
+    def load_weights_from_keras(self, weights):
+        """Weights of the original (TensorFlow / Keras) NeRF release: a list of numpy arrays [kernel, bias] per layer, kernels
+        as [in, out] — pts_linears 0..D-1, feature_linear, views_linears.0, rgb_linear, alpha_linear
+        (DS_NeRF/run_nerf_helpers.py:129-156; the reference asserts use_viewdirs as well)."""
+        assert self.use_viewdirs, "Not implemented if use_viewdirs=False"
+        import numpy as np
+        D = self.D
+        order = [f"pts_linears.{i}" for i in range(D)] + ["feature_linear", "views_linears.0", "rgb_linear", "alpha_linear"]
+        views = self.named_views(self.flat.detach())
+        with torch.no_grad():
+            for j, name in enumerate(order):
+                w = torch.from_numpy(np.ascontiguousarray(np.transpose(weights[2 * j]))).to(self.flat)
+                b = torch.from_numpy(np.ascontiguousarray(np.transpose(weights[2 * j + 1]))).to(self.flat)
+                if tuple(w.shape) != tuple(views[name + ".weight"].shape) or b.numel() != views[name + ".bias"].numel():
+                    raise ValueError(f"{name}: keras kernel {tuple(weights[2 * j].shape)} does not fit {tuple(views[name + '.weight'].shape)}")
+                views[name + ".weight"].copy_(w)
+                views[name + ".bias"].copy_(b.reshape(-1))
+        self.mark_weights_changed()
+
     # ---- evaluation ----------------------------------------------------------------------------
     def query(self, inputs, viewdirs=None):
         """inputs [..., S, 3] sample positions, viewdirs [..., 3] per ray -> raw [..., S, out_ch]."""

@@ -181,3 +181,46 @@ def test_resume_from_a_per_layer_adam_without_state_for_the_unused_views_layer(m
     extra = {"state": st_extra, "param_groups": osd["param_groups"]}
     with pytest.raises(RuntimeError, match="parameter indices"):
         tr.load_state_dict(dict(ck, optimizer_state_dict=extra))
+
+
+def test_create_nerf_refuses_an_unsupported_network_shape_by_flag_name(tmp_path):
+    """run_nerf.py:393-421 builds NeRF(D=args.netdepth, W=args.netwidth, ...); the HIP kernels implement the defaults (8 x 256,
+    skips [4]).  Anything else is refused by create_nerf with the FLAG's name, before any allocation or launch."""
+    import argparse
+    import pytest
+    import spin_nerf_amd as S
+    (tmp_path / "run").mkdir()
+    base = dict(multires=10, multires_views=4, i_embed=0, use_viewdirs=True, N_importance=128, N_samples=64,
+                alpha_model_path=None, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536,
+                lrate=1e-3, basedir=str(tmp_path), expname="run", ft_path=None, no_reload=True, perturb=1.0,
+                white_bkgd=True, raw_noise_std=1.0, dataset_type="llff", no_ndc=True, lindisp=True, sigma_loss=False,
+                no_coarse=False)
+    for flag, value in (("netwidth", 128), ("netdepth", 6), ("netwidth_fine", 512), ("netdepth_fine", 4), ("multires", 12)):
+        with pytest.raises(NotImplementedError, match=f"--{flag} {value}"):
+            S.create_nerf(argparse.Namespace(**dict(base, **{flag: value})), device=torch.device("cpu"))
+    S.create_nerf(argparse.Namespace(**base), device=torch.device("cpu"))   # the defaults build
+
+
+def test_load_weights_from_keras_transposes_into_the_flat_buffer():
+    """DS_NeRF/run_nerf_helpers.py:129-156: [kernel [in, out], bias] pairs in the order pts_linears 0..7, feature_linear,
+    views_linears.0, rgb_linear, alpha_linear."""
+    import numpy as np
+    import pytest
+    import spin_nerf_amd as S
+    net = S.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True)
+    rs = np.random.RandomState(0)
+    order = [f"pts_linears.{i}" for i in range(8)] + ["feature_linear", "views_linears.0", "rgb_linear", "alpha_linear"]
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    weights = []
+    for name in order:
+        fout, fin = shapes[name + ".weight"]
+        weights += [rs.normal(size=(fin, fout)).astype(np.float32), rs.normal(size=(fout,)).astype(np.float32)]
+    gen = net.weights_generation
+    net.load_weights_from_keras(weights)
+    sd = net.state_dict()
+    for j, name in enumerate(order):
+        assert np.array_equal(sd[name + ".weight"].numpy(), weights[2 * j].T)
+        assert np.array_equal(sd[name + ".bias"].numpy(), weights[2 * j + 1])
+    assert net.weights_generation == gen + 1       # the packed-weight cache is invalidated
+    with pytest.raises(AssertionError):
+        S.NeRF(input_ch=63, input_ch_views=0, use_viewdirs=False, output_ch=5).load_weights_from_keras(weights)
