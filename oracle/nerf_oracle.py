@@ -163,24 +163,45 @@ def _bf16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-def nerf_forward_bf16emu(sd, x, input_ch=63, input_ch_views=27, skips=(4,), use_viewdirs=True):
+def _f16(t: torch.Tensor) -> torch.Tensor:
+    """Round-to-nearest-even to fp16 and back (v_cvt_pk_f16_f32)."""
+    return t.to(torch.float16).to(torch.float32)
+
+
+def nerf_forward_bf16emu(sd, x, input_ch=63, input_ch_views=27, skips=(4,), use_viewdirs=True, enc_f16=True):
     """Same network with the HIP bf16 kernel's rounding points emulated: weights and
     every MFMA *input* activation rounded to bf16, accumulation / bias / ReLU in fp32.
-    Used to hold the bf16 kernel to a tight tolerance instead of a loose fp32 one."""
+    Used to hold the bf16 kernel to a tight tolerance instead of a loose fp32 one.
+
+    Round 6 (spin-nerf_amd/csrc/mlp_layout.h: EncF16): the positional / directional encodings, and the weight COLUMNS that
+    multiply them (all of pts_linears.0, the first input_ch columns of the skip layer, the last input_ch_views columns of
+    views_linears.0), are fp16 instead of bf16 — the same MFMA rate with 11 mantissa bits where the inputs live in [-1, 1].
+    ``enc_f16=False`` is the round-5 arithmetic (everything bf16)."""
     q = _bf16
+    qe = _f16 if enc_f16 else _bf16
     input_pts, input_views = torch.split(x, [input_ch, input_ch_views], dim=-1)
-    input_pts, input_views = q(input_pts), q(input_views)
+    input_pts, input_views = qe(input_pts), qe(input_views)
     D = len([k for k in sd if k.startswith("pts_linears.") and k.endswith(".weight")])
     h = input_pts
     for i in range(D):
-        h = q(F.relu(F.linear(h, q(sd[f"pts_linears.{i}.weight"]), sd[f"pts_linears.{i}.bias"])))
+        W = sd[f"pts_linears.{i}.weight"]
+        if i == 0:
+            Wq = qe(W)
+        elif (i - 1) in skips:                      # input = cat([input_pts, h]) (helpers:110-111)
+            Wq = torch.cat([qe(W[:, :input_ch]), q(W[:, input_ch:])], -1)
+        else:
+            Wq = q(W)
+        h = q(F.relu(F.linear(h, Wq, sd[f"pts_linears.{i}.bias"])))
         if i in skips:
             h = torch.cat([input_pts, h], -1)
     if use_viewdirs:
         alpha = F.linear(h, q(sd["alpha_linear.weight"]), sd["alpha_linear.bias"])
         feature = q(F.linear(h, q(sd["feature_linear.weight"]), sd["feature_linear.bias"]))
         h = torch.cat([feature, input_views], -1)
-        h = q(F.relu(F.linear(h, q(sd["views_linears.0.weight"]), sd["views_linears.0.bias"])))
+        Wv = sd["views_linears.0.weight"]
+        nv = Wv.shape[1] - input_ch_views           # input = cat([feature, input_views]) (helpers:119)
+        Wvq = torch.cat([q(Wv[:, :nv]), qe(Wv[:, nv:])], -1)
+        h = q(F.relu(F.linear(h, Wvq, sd["views_linears.0.bias"])))
         rgb = F.linear(h, q(sd["rgb_linear.weight"]), sd["rgb_linear.bias"])
         return torch.cat([rgb, alpha], -1)
     return F.linear(h, q(sd["output_linear.weight"]), sd["output_linear.bias"])

@@ -181,7 +181,9 @@ __global__ __launch_bounds__(kApThreads) void adam_pack_kernel(AdamPackArgs a) {
     for (int e = 0; e < EPF; ++e) {
       const int slot = slot_of<P>(S.kind, f, g, e, T.multires, T.multires_views);
       const float v = (i < nrows && slot >= 0) ? W[i * kPanelLd + S.col_off + slot] : 0.f;
-      Mma<P>::set(out, e, v);
+      // (bf16 mode: the columns that multiply an encoding are fp16 — mlp_fwd.hip: mlp_pack_kernel, bit for bit)
+      if (EncF16<P>::value && (S.kind == SRC_ENC_PTS || S.kind == SRC_ENC_DIR)) Mma<P>::set_f16(out, e, v);
+      else Mma<P>::set(out, e, v);
     }
     const int64_t F = E.frag_begin + tile * per_tile + fl;
     *(Frag*)(N.blob + (F * 64 + lane) * 16) = out;

@@ -25,7 +25,6 @@
 #include "mlp_device.h"
 #include "mlp_wgrad.h"
 #include "mlp_wgrad_pair.h"
-#include "mlp_chain2.h"
 
 namespace snr {
 
@@ -229,155 +228,6 @@ __global__ __launch_bounds__((64 * ChainCfg<P, true>::WAVES)) void mlp_dgrad_ker
 }
 
 
-// ------------------------------------------------------------------------------------------
-// 1b. chain2 dgrad (bf16, view directions, selective recompute): 8 compute waves + 2 loaders + 2 storers, mlp_chain2.h
-// ------------------------------------------------------------------------------------------
-// chunk list of a pass, in staging order: d out (1 fragment, last spill slot), the 4 tiles of d z9, the 8 tiles each of
-// d z7, d z5, d z3, d z1.  A tile t is staged in slot t (t < NREG: a register-resident tile, the slot is rewritten by tile
-// t + NREG) or in its own spill slot t - NREG.  Sections: 0 d out, 1 d z9, 2 + j d z(7 - 2 j).
-struct Dgrad2Table {
-  static constexpr int kChunks = c2::BwdMap::kChunks;
-  static constexpr c2::Chunk chunk(int c) {
-    if (c == 0) return c2::Chunk{0, 0, 1, c2::kSpillTiles - 1};
-    const int q = c < 5 ? c - 1 : (c - 5) % 8;
-    return c2::Chunk{c < 5 ? 1 : 2 + (c - 5) / 8, 2 * q, 2, q < c2::kNReg ? q : q - c2::kNReg};
-  }
-};
-
-__global__ __launch_bounds__((64 * c2::kWaves)) void mlp_dgrad2_kernel(DgradMulti mm) {
-  using namespace c2;
-  const DgradArgs& a = mm.net[(mm.n > 1 && (int)blockIdx.x >= mm.net[1].block0) ? 1 : 0];
-  using B = Blob<kBF16>;
-  constexpr int P = kBF16, KS_H = B::KS_H, KS_H9 = B::KS_H9, NREG = kNReg;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ring = smem + kBiasBytes;
-  char* spill0 = smem + kBiasBytes + kRing2Bytes;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  LdsFlags fl = (LdsFlags)SNR_LDS(smem + kFlagsOffset);
-  if (tid < (int)(sizeof(Flags) / 4)) ((LdsWord)fl)[tid] = 0u;
-  if ((int)blockIdx.x == a.block0 && a.zero_words && tid < a.n_zero) a.zero_words[tid] = 0u;
-  __syncthreads();
-
-  const ActLayout<P> AL(a.n_samples, true);
-  const WsLayout<P> WL(a.n_samples, true);
-  const int64_t n_wg = AL.n_tiles / kCompute;
-  const int first = (int)blockIdx.x - a.block0;
-  const int n_pass = first < n_wg ? (int)((n_wg - first + a.blocks - 1) / a.blocks) : 0;
-
-  if (wave >= kCompute + 2) {          // storers
-    storer_run<Dgrad2Table>(spill0, fl, wave - kCompute - 2, lane, n_pass, [&](int sec, int pass, int w) {
-      const int64_t tile = ((int64_t)first + (int64_t)pass * a.blocks) * kCompute + w;
-      const int k = sec == 0 ? WL.k_dout() : (sec == 1 ? WL.k_dz9() : WL.k_dz(7 - 2 * (sec - 2)));
-      const int n = sec == 0 ? 1 : (sec == 1 ? KS_H9 : KS_H);
-      return a.ws + (WL.n_tiles * k + tile * n) * 1024;
-    });
-    return;
-  }
-  if (wave >= kCompute) {              // loaders
-    loader_run<2>(ring, fl, a.blob_bwd, BwdMap::kBlocks, BwdMap::kPassBlocks, n_pass, wave - kCompute, lane);
-    return;
-  }
-
-  const int sj = lane & 31, g = lane >> 5;
-  Cw<2> cw;
-  cw.ring_lane = ring + lane * 16;
-  cw.spill_lane = spill0 + wave * kSpillBytes + lane * 16;
-  cw.bias_lds = nullptr;
-  cw.fl = fl;
-  cw.my_done = &fl->done[wave];
-  cw.my_staged = &fl->staged[wave];
-  cw.my_stored = &fl->stored[wave];
-  cw.g = g;
-  cw.seen[0] = cw.seen[1] = 0;
-  cw.base = 0;
-  cw.n_staged = cw.seen_stored = 0;
-#pragma unroll
-  for (int i = 0; i < kSpillTiles; ++i) cw.slot_chunk[i] = 0;
-
-  for (int64_t wg = first; wg < n_wg; wg += a.blocks) {
-    const int64_t tile0 = wg * kCompute + wave;
-    // d raw -> OUT fragment: k-slot 8 g + e = channel (mlp_dgrad_kernel)
-    Frag dout = Mma<P>::zero();
-    {
-      const int64_t m = tile0 * 32 + sj;
-      if (m < a.n_samples) {
-        const float* dr = a.d_raw + m * a.out_ch;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int ch = 8 * g + e;
-          if (ch < a.out_ch) Mma<P>::set(dout, e, dr[ch]);
-        }
-      }
-    }
-    auto mask_of = [&](int k_sec) { return *((const u32x4*)(a.act + (AL.n_tiles * k_sec + tile0) * 1024) + lane); };
-    u32x4 mk = mask_of(AL.k_mask9()), mk_next = mask_of(AL.k_mask(7));
-
-    Frag in[KS_H], outr[2 * NREG];
-    // epilogue of an output tile: relu' mask, two fragments; SAVED: the tile is a chunk for the storers
-    auto tile_out = [&](auto SAVED_, auto MASK_, auto LAST_, auto NT_, const f32x16& acc) {
-      constexpr int nt = decltype(NT_)::value;
-      constexpr bool SAVED = decltype(SAVED_)::value, LAST = decltype(LAST_)::value;
-      Frag o[2];
-      finish_dgrad_bf16(acc, o, decltype(MASK_)::value, mk[nt >> 1], 8 * (nt & 1));
-      constexpr int slot = nt < NREG ? nt : nt - NREG;
-      if constexpr (nt < NREG) { outr[2 * nt] = o[0]; outr[2 * nt + 1] = o[1]; }
-      if constexpr (LAST) { in[2 * nt] = o[0]; in[2 * nt + 1] = o[1]; }   // the stage's input is dead: no reload of the last tile
-      if constexpr (SAVED || (nt >= NREG && !LAST)) {
-        cw.slot_free<slot>();
-        cw.spill_write<slot, 0>(o[0]); cw.spill_write<slot, 1>(o[1]);
-        if constexpr (SAVED) cw.post_chunk<slot>();
-      }
-    };
-    auto next_in = [&](auto NT_) {
-      constexpr int NT = decltype(NT_)::value;
-      static_for<0, 2 * NT>([&](auto F_) {
-        constexpr int f = decltype(F_)::value;
-        if constexpr (f < 2 * NREG) in[f] = outr[f];
-        else if constexpr (f >= 2 * NT - 2) {}   // the last tile went straight to in[]
-        else in[f] = cw.spill_read<(f - 2 * NREG) / 2, (f - 2 * NREG) % 2>();
-      });
-    };
-    using TT = std::true_type;
-    using FF = std::false_type;
-    using I8 = std::integral_constant<int, 8>;
-    using I4 = std::integral_constant<int, 4>;
-
-    // chunk 0: d out, one fragment in the last spill slot
-    cw.slot_free<kSpillTiles - 1>();
-    cw.spill_write<kSpillTiles - 1, 0>(dout);
-    cw.post_chunk<kSpillTiles - 1>();
-    // d z9 = relu'(h9) * (W_rgb^T d rgb): 4 tiles
-    cw.stage<BwdMap::B0, BwdMap::N0, 1, 0, 4, false>(&dout, &dout, 0, [&](auto NT_, f32x16& acc) {
-      tile_out(TT{}, TT{}, std::integral_constant<bool, decltype(NT_)::value == 3>{}, NT_, acc);
-    });
-    next_in(I4{});
-    mk = mk_next; mk_next = mask_of(AL.k_mask(6));
-    // d feat = W_views[:, :256]^T d z9: not saved (its weight gradient follows from d z9: mlp_wgrad.h), no relu in front of it
-    cw.stage<BwdMap::B1, BwdMap::N1, KS_H9, 0, 8, false>(in, in, 0, [&](auto NT_, f32x16& acc) {
-      tile_out(FF{}, FF{}, std::integral_constant<bool, decltype(NT_)::value == 7>{}, NT_, acc);
-    });
-    next_in(I8{});
-    // d z7 = relu'(h7) * (W_feat^T d feat + W_alpha^T d alpha)
-    cw.stage<BwdMap::B2, BwdMap::N2, KS_H, 1, 8, false>(in, &dout, 0, [&](auto NT_, f32x16& acc) {
-      tile_out(TT{}, TT{}, std::integral_constant<bool, decltype(NT_)::value == 7>{}, NT_, acc);
-    });
-    next_in(I8{});
-    // d z_{6-j} = relu'(h_{6-j}) * (W_{7-j}^T d z_{7-j}), j = 0..5; the odd ones are saved
-    static_for<0, 6>([&](auto J_) {
-      constexpr int j = decltype(J_)::value;
-      mk = mk_next;
-      if constexpr (j < 5) mk_next = mask_of(AL.k_mask(5 - j));
-      cw.stage<BwdMap::B3 + j * BwdMap::NH, BwdMap::NH, KS_H, 0, 8, false>(in, in, 0, [&](auto NT_, f32x16& acc) {
-        tile_out(std::integral_constant<bool, (j & 1) == 1>{}, TT{}, std::integral_constant<bool, decltype(NT_)::value == 7>{}, NT_, acc);
-      });
-      if constexpr (j < 5) next_in(I8{});
-    });
-    cw.base += BwdMap::kPassBlocks;
-  }
-}
-
 }  // namespace snr
 
 int snr::wgrad_launch_bf16(const WgradArgs& w, int total_splits, float* grad, int accumulate, hipStream_t s) {
@@ -465,26 +315,6 @@ static int launch_dgrad(DgradMulti& m, hipStream_t s) {
   {
     ProfScope ps(K_MLP_DGRAD, s);
     mlp_dgrad_kernel<P, VD, SAVE_EVEN><<<dim3((unsigned)block), dim3(64 * ChainCfg<P, true>::WAVES), lds, s>>>(m);
-  }
-  return launch_status();
-}
-
-// chain2: persistent workgroups (one per CU), shared out in proportion to the networks' tiles
-static int launch_dgrad2(DgradMulti& m, hipStream_t s) {
-  int64_t n_wg[kMaxReduceNets], total = 0;
-  for (int i = 0; i < m.n; ++i) { n_wg[i] = padded_tiles<kBF16>(m.net[i].n_samples) / c2::kCompute; total += n_wg[i]; }
-  const int64_t budget = cu_count();
-  int block = 0;
-  for (int i = 0; i < m.n; ++i) {
-    int64_t g = total <= budget ? n_wg[i] : n_wg[i] * budget / total;
-    if (g < 1) g = 1;
-    m.net[i].block0 = block; m.net[i].blocks = (int)g; block += (int)g;
-  }
-  const int lds = c2::kBiasBytes + c2::kRing2Bytes + c2::kCompute * c2::kSpillBytes;
-  if (int e = ensure_dynamic_lds<&mlp_dgrad2_kernel>(lds)) return e;
-  {
-    ProfScope ps(K_MLP_DGRAD, s);
-    mlp_dgrad2_kernel<<<dim3((unsigned)block), dim3(64 * c2::kWaves), lds, s>>>(m);
   }
   return launch_status();
 }
@@ -587,8 +417,7 @@ static int backward_merged(const BwdItem* items, int n, hipStream_t s) {
     if (!append_reduce(ra, nets[i].red, i, it.grad_params, it.accumulate)) return SNR_ERR_UNSUPPORTED;
     post.net[i] = post_net(it, g_block);
   }
-  if (vd && tunables().chain2) st = launch_dgrad2(m, s);
-  else st = vd ? launch_dgrad<P, true, false>(m, s) : launch_dgrad<P, false, false>(m, s);
+  st = vd ? launch_dgrad<P, true, false>(m, s) : launch_dgrad<P, false, false>(m, s);
   if (st != SNR_OK) return st;
   if (int e = ensure_dynamic_lds<&mlp_wgrad_pair_kernel>(kLdsBytes)) return e;
   {

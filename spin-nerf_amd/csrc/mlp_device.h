@@ -209,7 +209,9 @@ template <int P, int WAVES_> struct Pipe {
   //    straight after its tile (keeping the previous accumulator measured no gain and costs 16 registers);
   //  * pre(nt) issues tile nt's slice of the deferred global stores (the previous stage's output):
   //    spread over the tiles so that no burst of stores sits in front of the counted DMA waits.
-  template <int KA, int KB, int NT, int NJ, int SA, int SB, class Init, class Finish, class Pre>
+  //  * A16 / B16: the first / second source's fragments (and their weight fragments) are fp16: that segment's MFMAs are
+  //    v_mfma_f32_32x32x16_f16 into the same accumulator (the encodings of the bf16 mode, mlp_layout.h: EncF16).
+  template <int KA, int KB, int NT, int NJ, int SA, int SB, bool A16 = false, bool B16 = false, class Init, class Finish, class Pre>
   __device__ __forceinline__ void run_tiles(const Frag* sa, const Frag* sb, Init&& init, Finish&& finish, Pre&& pre) {
     constexpr int K = KA + KB, NF = NT * K;
 #ifndef SNR_WINDOW
@@ -276,7 +278,7 @@ template <int P, int WAVES_> struct Pipe {
 #ifndef SNR_TWO_CHAIN
 #define SNR_TWO_CHAIN 0   // A/B builds (round 4): 1 = the dgrad chains (no bias, bf16) accumulate even and odd k-steps of an output
 #endif                    // tile in two independent accumulators (tests/probes/mfma_feed.hip: 82 % vs 75 % of the MFMA rate)
-      constexpr bool TWO = SNR_TWO_CHAIN && !BIAS && P == kBF16 && K >= 4 && NJ == 1;
+      constexpr bool TWO = SNR_TWO_CHAIN && !BIAS && P == kBF16 && K >= 4 && NJ == 1 && !A16 && !B16;
       f32x16 acc2;   // (TWO) the odd k-steps' chain; its first MFMA takes the constant 0 as C
       static_for<0, K>([&](auto F_) {
         constexpr int f = decltype(F_)::value;
@@ -298,8 +300,13 @@ template <int P, int WAVES_> struct Pipe {
         } else {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            if constexpr (f < KA) acc[j] = M::mma(w[i % G], sa[j * SA + f], acc[j]);
-            else acc[j] = M::mma(w[i % G], sb[j * SB + (f - KA)], acc[j]);
+            if constexpr (f < KA) {
+              if constexpr (A16) acc[j] = M::mma_f16(w[i % G], sa[j * SA + f], acc[j]);
+              else acc[j] = M::mma(w[i % G], sa[j * SA + f], acc[j]);
+            } else {
+              if constexpr (B16) acc[j] = M::mma_f16(w[i % G], sb[j * SB + (f - KA)], acc[j]);
+              else acc[j] = M::mma(w[i % G], sb[j * SB + (f - KA)], acc[j]);
+            }
           }
         }
         if constexpr (f == 0) {
@@ -454,7 +461,9 @@ __device__ __forceinline__ void store16_stream(const char* sbase, uint32_t voff,
 #ifndef SNR_STORE_SPLIT
 #define SNR_STORE_SPLIT 1
 #endif
-template <int P, int N, int NT, int PAR = -1, class Frag>
+// CVT16: the fragments are fp16 (an encoding of the bf16 mode) and are saved re-rounded to bf16 — the conversion sits inside the
+// store's own branch, so a fragment is converted by the output tile that stores it and no second copy of the encoding is live.
+template <int P, int N, int NT, int PAR = -1, bool CVT16 = false, class Frag>
 __device__ __forceinline__ void store_tile_slice(const char* tile_base, const Frag* src, int nt, uint32_t lane_even, uint32_t lane_odd) {
   constexpr int M = PAR < 0 ? N : (PAR == 0 ? (N + 1) / 2 : N / 2);   // fragments this call may store
   static_for<0, M>([&](auto I_) {
@@ -468,12 +477,20 @@ __device__ __forceinline__ void store_tile_slice(const char* tile_base, const Fr
 #else
     if (idx >= M * nt / NT && idx < M * (nt + 1) / NT)
 #endif
-      store16_stream<(f % 4) * 1024>(tile_base + (f / 4) * 4096, (f & 1) ? lane_odd : lane_even, src[f]);
+    {
+      if constexpr (CVT16) store16_stream<(f % 4) * 1024>(tile_base + (f / 4) * 4096, (f & 1) ? lane_odd : lane_even, Mma<P>::f16_to_bf16(src[f]));
+      else store16_stream<(f % 4) * 1024>(tile_base + (f / 4) * 4096, (f & 1) ? lane_odd : lane_even, src[f]);
+    }
   });
 }
 
 // sin/cos encoding of one 3-vector into KS frags (mlp_layout.h: enc_slot_feature)
-template <int P, int KS>
+// F16: the fragment holds fp16 values (bf16 mode, mlp_layout.h: EncF16) instead of the mode's own element type
+template <int P, bool F16> __device__ __forceinline__ void enc_set(typename Mma<P>::Frag& f, int e, float x) {
+  if constexpr (F16) Mma<P>::set_f16(f, e, x);
+  else Mma<P>::set(f, e, x);
+}
+template <int P, int KS, bool F16 = false>
 __device__ __forceinline__ void encode(float x, float y, float z, int L, int g, typename Mma<P>::Frag* out) {
   constexpr int HP = Prec<P>::EPF / 2;
   // Everything below that depends only on (g, L) — slot indices, axis selectors, 2^k — is invariant across the tile
@@ -506,8 +523,8 @@ __device__ __forceinline__ void encode(float x, float y, float z, int L, int g, 
       } else if (p == 3 * L + 1) {
         s = z;
       }
-      Mma<P>::set(f, 2 * pp, s);
-      Mma<P>::set(f, 2 * pp + 1, c);
+      enc_set<P, F16>(f, 2 * pp, s);
+      enc_set<P, F16>(f, 2 * pp + 1, c);
     }
     out[q] = f;
   }
@@ -521,7 +538,7 @@ __device__ __forceinline__ void encode(float x, float y, float z, int L, int g, 
 // candidates of every pair (g = 0 / 1) are compile-time constants and the lane picks with one v_cndmask each: input
 // coordinate, scale 2^k / 2 pi (ONE multiplication: scaling by a power of two is exact, so fl(x 2^k c) is the same number the
 // generic version rounds to — the results are bit-identical, tests/test_gpu_kernels.py), then floor / sub / sin / cos.
-template <int P, int KS, int LT>
+template <int P, int KS, int LT, bool F16 = false>
 __device__ __forceinline__ void encode_static(float x, float y, float z, int g, typename Mma<P>::Frag* out) {
   static_assert(P == kBF16, "hardware sin / cos: bf16 mode only");
   constexpr int HP = Prec<P>::EPF / 2;
@@ -558,23 +575,23 @@ __device__ __forceinline__ void encode_static(float x, float y, float z, int g, 
         const float s1 = kind1 == 1 ? x : (kind1 == 2 ? z : 0.f), c1 = kind1 == 1 ? y : 0.f;
         s = hi ? s1 : s; c = hi ? c1 : c;
       }
-      Mma<P>::set(f, 2 * pp, s);
-      Mma<P>::set(f, 2 * pp + 1, c);
+      enc_set<P, F16>(f, 2 * pp, s);
+      enc_set<P, F16>(f, 2 * pp + 1, c);
     });
     out[q] = f;
   });
 }
 // bf16 with the reference's frequency counts takes the static version (a wave-uniform branch); everything else the generic one
 // (Lsel: L, or -1 to force the generic version — SNR_ENC_GENERIC, the bit-identity test)
-template <int P, int KS, int LT>
+template <int P, int KS, int LT, bool F16 = false>
 __device__ __forceinline__ void encode_auto(float x, float y, float z, int Lsel, int L, int g, typename Mma<P>::Frag* out) {
 #ifndef SNR_ENC_STATIC
 #define SNR_ENC_STATIC 1   // A/B builds: 0 = the generic encoding everywhere
 #endif
   if constexpr (P == kBF16 && SNR_ENC_STATIC) {
-    if (Lsel == LT) { encode_static<P, KS, LT>(x, y, z, g, out); return; }
+    if (Lsel == LT) { encode_static<P, KS, LT, F16>(x, y, z, g, out); return; }
   }
-  encode<P, KS>(x, y, z, L, g, out);
+  encode<P, KS, F16>(x, y, z, L, g, out);
 }
 
 }  // namespace snr

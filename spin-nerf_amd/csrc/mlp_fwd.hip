@@ -14,7 +14,6 @@
 #include "snr_common.h"
 #include "mlp_pack.h"
 #include "mlp_device.h"
-#include "mlp_chain2.h"
 
 namespace snr {
 
@@ -63,7 +62,9 @@ __global__ void mlp_pack_kernel(PackTable T, const float* __restrict__ params, c
           if (n >= 0 && n < S.n_valid) v = params[S.w_off + (int64_t)n * S.ld + S.col_off + row];
         }
       }
-      Mma<P>::set(out, e, v);
+      // (bf16 mode: the columns that multiply an encoding are fp16, like the encoding itself — mlp_layout.h: EncF16)
+      if (EncF16<P>::value && (S.kind == SRC_ENC_PTS || S.kind == SRC_ENC_DIR)) Mma<P>::set_f16(out, e, v);
+      else Mma<P>::set(out, e, v);
     }
     *(Frag*)(blob + ((int64_t)F * 64 + lane) * 16) = out;
   }
@@ -233,6 +234,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     // bf16 re-derives them where they are consumed (hardware sin/cos, ~200 instructions) — `fresh`
     // hides the inputs from common-subexpression elimination so the first copy really dies.
     constexpr bool kKeepEnc = P == kFP32;
+    constexpr bool E16 = EncF16<P>::value;   // the encodings (and the weight columns they meet) are fp16 in bf16 mode
     Frag pe[NJ][KS_PE];
     Frag dir[NJ][KS_DIRA];
     auto make_pe = [&](bool fresh) {
@@ -240,7 +242,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
       for (int jt = 0; jt < NJ; ++jt) {
         float x = px[jt], y = py[jt], z = pz[jt];
         if (fresh) asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-        encode_auto<P, KS_PE, kMaxMultires>(x, y, z, a.enc_generic ? -1 : a.multires, a.multires, g, pe[jt]);
+        encode_auto<P, KS_PE, kMaxMultires, E16>(x, y, z, a.enc_generic ? -1 : a.multires, a.multires, g, pe[jt]);
       }
     };
     auto make_dir = [&](bool fresh) {
@@ -249,7 +251,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
         for (int jt = 0; jt < NJ; ++jt) {
           float x = dx[jt], y = dy[jt], z = dz[jt];
           if (fresh) asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-          encode_auto<P, KS_DIR, kMaxMultiresViews>(x, y, z, a.enc_generic ? -1 : a.multires_views, a.multires_views, g, dir[jt]);
+          encode_auto<P, KS_DIR, kMaxMultiresViews, E16>(x, y, z, a.enc_generic ? -1 : a.multires_views, a.multires_views, g, dir[jt]);
         }
       }
     };
@@ -267,11 +269,14 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
 #endif
       return a.act + (AL.n_tiles * k_sec + tile * n) * 1024;
     };
-    auto act_store_par = [&](auto PAR_, int k_sec, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
+    auto act_store_cvt = [&](auto CVT_, auto PAR_, int k_sec, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
       constexpr int n = decltype(N_)::value, stride = decltype(STRIDE_)::value, NT = decltype(NT_)::value;
 #pragma unroll
       for (int jt = 0; jt < NJ; ++jt)
-        store_tile_slice<P, n, NT, decltype(PAR_)::value>(sec_base(k_sec, tile0 + jt, n), src + jt * stride, nt, lane_even, lane_odd);
+        store_tile_slice<P, n, NT, decltype(PAR_)::value, decltype(CVT_)::value>(sec_base(k_sec, tile0 + jt, n), src + jt * stride, nt, lane_even, lane_odd);
+    };
+    auto act_store_par = [&](auto PAR_, int k_sec, auto N_, const Frag* src, auto STRIDE_, int nt, auto NT_) {
+      act_store_cvt(std::false_type{}, PAR_, k_sec, N_, src, STRIDE_, nt, NT_);
     };
     using PALL = std::integral_constant<int, -1>;
     // a saved hidden layer's even fragments are stored by the stage that produces them, the odd ones by the next stage (mlp_device.h)
@@ -319,12 +324,14 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
       for (int jt = 0; jt < NJ; ++jt) mask[jt] = u32x4{0, 0, 0, 0};
     };
     // ---- generic 8-tile stage: dst = [relu](W [sa|sb] + b); sources / dst have per-sample-tile strides ----
+    // (a stage whose FIRST source is an encoding — stages 0 and 5 — multiplies that segment in fp16: KA == KS_PE marks it)
     auto stage8 = [&](auto KA_, auto KB_, auto SA_, auto SB_, const Frag* sa, const Frag* sb, Frag* dst, int bias_off,
                       auto&& pre, int s_out) {
       constexpr int KA = decltype(KA_)::value, KB = decltype(KB_)::value;
       constexpr int SA = decltype(SA_)::value, SB = decltype(SB_)::value;
+      constexpr bool A16 = E16 && KA == KS_PE;
       clear_masks();
-      pipe.template run_tiles<KA, KB, 8, NJ, SA, SB>(
+      pipe.template run_tiles<KA, KB, 8, NJ, SA, SB, A16, false>(
           sa, sb, [&](int nt) { return bias_tile_addr(bias_lds, bias_off + 32 * nt, g); },
           [&](int nt, int jt, f32x16 acc) {
             tile_out(std::true_type{}, nt, jt, acc, dst + jt * KS_H + nt * FPT);
@@ -341,8 +348,9 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
     // stage 0: PE -> hA
     stage8(IPE{}, I0{}, IPE{}, IPE{}, &pe[0][0], &pe[0][0], &hA[0][0], bias_off_stage(0), [&](int nt) {
       if constexpr (TRAIN) {
-        act_store(AL.k_pe(), IPE{}, &pe[0][0], IPE{}, nt, I8{});
-        if constexpr (VD) act_store(AL.k_dir(), IDIR{}, &dir[0][0], IDIRA{}, nt, I8{});
+        // (the saved encodings are bf16 whatever the forward multiplied with: the weight-gradient pass pairs them with d z)
+        act_store_cvt(std::bool_constant<E16>{}, PALL{}, AL.k_pe(), IPE{}, &pe[0][0], IPE{}, nt, I8{});
+        if constexpr (VD) act_store_cvt(std::bool_constant<E16>{}, PALL{}, AL.k_dir(), IDIR{}, &dir[0][0], IDIRA{}, nt, I8{});
       }
     }, 0);
     // stages 1..7 ping-pong hA/hB; stage 5 prepends the encoding (skip connection, helpers:110-111)
@@ -410,7 +418,7 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
 #ifdef SNR_TIMING
       pipe.t_phase[2] += SNR_T() - tp2;
 #endif
-      pipe.template run_tiles<KS_H, KS_DIR, 4, NJ, KS_H, KS_DIRA>(
+      pipe.template run_tiles<KS_H, KS_DIR, 4, NJ, KS_H, KS_DIRA, false, E16>(
           feat, &dir[0][0], [&](int nt) { return bias_tile_addr(bias_lds, kBiasViews + 32 * nt, g); },
           [&](int nt, int jt, f32x16 acc) {
             tile_out(std::true_type{}, nt, jt, acc, h9 + jt * KS_H + nt * FPT);
@@ -462,140 +470,6 @@ __global__ __launch_bounds__((64 * ChainCfg<P, TRAIN>::WAVES)) void mlp_fwd_kern
   pipe.drain();  // prefetched blocks still in flight must land before the LDS allocation is released
 }
 
-
-// ------------------------------------------------------------------------------------------
-// chain2 forward (bf16, view directions): 8 compute waves + 4 helper waves, mlp_chain2.h
-// ------------------------------------------------------------------------------------------
-#ifndef SNR_C2_WPE
-#define SNR_C2_WPE 1
-#endif
-template <bool TRAIN>
-__global__ __launch_bounds__((64 * c2::kWaves), SNR_C2_WPE) void mlp_fwd2_kernel(FwdArgs a) {
-  using namespace c2;
-  using B = Blob<kBF16>;
-  constexpr int P = kBF16, KS_H = B::KS_H, KS_PE = B::KS_PE, KS_DIR = B::KS_DIR, KS_H9 = B::KS_H9;
-  constexpr int NREG = kNReg;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* bias_lds = (float*)smem;
-  char* ring = smem + kBiasBytes;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < a.bias_floats; i += 64 * kWaves) bias_lds[i] = a.bias[i];
-  LdsFlags fl = (LdsFlags)SNR_LDS(smem + kFlagsOffset);
-  if (tid < (int)(sizeof(Flags) / 4)) ((LdsWord)fl)[tid] = 0u;
-  __syncthreads();   // bias block and cleared progress words visible to all waves (nothing is in flight yet)
-
-  const ActLayout<P> AL(a.n_samples, true);
-  const int64_t n_wg = (AL.n_tiles + kCompute - 1) / kCompute;
-  const int n_pass = (int)((n_wg - (int64_t)blockIdx.x + gridDim.x - 1) / gridDim.x);
-
-#if !(SNR_C2_ABLATE & 16)
-  if (wave >= kCompute) {
-    loader_run<kHelpers>(ring, fl, a.blob, FwdMap::kBlocks, FwdMap::kPassBlocks, n_pass, wave - kCompute, lane);
-    return;
-  }
-#endif
-
-  const int sj = lane & 31, g = lane >> 5;
-  Cw<4> cw;
-  cw.ring_lane = ring + lane * 16;
-  cw.spill_lane = smem + kBiasBytes + kRing2Bytes + wave * kSpillBytes + lane * 16;
-  cw.bias_lds = bias_lds;
-  cw.fl = fl;
-  cw.my_done = &fl->done[wave];
-  cw.g = g;
-  cw.seen[0] = cw.seen[1] = 0;
-  cw.my_staged = &fl->staged[wave];
-  cw.my_stored = &fl->stored[wave];
-  cw.n_staged = cw.seen_stored = 0;
-  cw.base = 0;
-
-  for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
-    const int64_t m = (wg * kCompute + wave) * 32 + sj;
-    const bool valid = m < a.n_samples;
-    float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-    if (valid) {
-      const int64_t ray = m / a.S;
-      if (a.pts) {
-        px = a.pts[3 * m]; py = a.pts[3 * m + 1]; pz = a.pts[3 * m + 2];
-      } else {
-        const float* r = a.rays + ray * a.ray_ld;
-        const float t = a.z_vals[m];
-        px = mul_add_unfused(r[3], t, r[0]);   // run_nerf.py:670-671, mlp_fwd_kernel
-        py = mul_add_unfused(r[4], t, r[1]);
-        pz = mul_add_unfused(r[5], t, r[2]);
-      }
-      const float* v = a.viewdirs + ray * a.vd_ld;
-      dx = v[0]; dy = v[1]; dz = v[2];
-    }
-    Frag in[KS_H], outr[2 * NREG], pe[KS_PE];
-    // epilogue of an output tile of an 8-tile stage: [relu] -> two fragments -> registers (tiles < NREG) or the spill slot
-    auto tile_out = [&](auto RELU_, auto NT_, const f32x16& acc) {
-      constexpr int nt = decltype(NT_)::value;
-      constexpr bool DIRECT = nt == 7 && !TRAIN && decltype(RELU_)::value;   // (the feature stage is the one without relu)
-      Frag o[2];
-      unsigned word = 0;
-      finish_fwd_bf16<decltype(RELU_)::value, false>(acc, o, word, 0);
-      if constexpr (nt < NREG) { outr[2 * nt] = o[0]; outr[2 * nt + 1] = o[1]; }
-      else if constexpr (DIRECT) { in[14] = o[0]; in[15] = o[1]; }   // the input is dead behind the last tile's MFMAs (not in
-                                                                      // the feature stage: its ninth tile still reads it)
-      else { cw.spill_write<nt - NREG, 0>(o[0]); cw.spill_write<nt - NREG, 1>(o[1]); }
-    };
-    auto relu_out = [&](auto NT_, f32x16& acc) { tile_out(std::true_type{}, NT_, acc); };
-    // the stage's output becomes the next stage's input: NT tiles = 2 NT fragments
-    auto next_in = [&](auto NT_, auto DIRECT_) {
-      constexpr int NT = decltype(NT_)::value;
-      static_for<0, 2 * NT>([&](auto F_) {
-        constexpr int f = decltype(F_)::value;
-        if constexpr (f < 2 * NREG) in[f] = outr[f];
-        else if constexpr (f >= 14 && !TRAIN && decltype(DIRECT_)::value) {}   // tile 7 went straight to in[14], in[15]
-        else in[f] = cw.spill_read<(f - 2 * NREG) / 2, (f - 2 * NREG) % 2>();
-      });
-    };
-    using I8 = std::integral_constant<int, 8>;
-    using I4 = std::integral_constant<int, 4>;
-
-    encode<P, KS_PE>(px, py, pz, a.multires, g, pe);
-    cw.stage<FwdMap::B0, FwdMap::N0, KS_PE, 0, 8>(pe, pe, bias_off_stage(0), relu_out);
-    next_in(I8{}, std::true_type{});
-    static_for<0, 4>([&](auto S_) {
-      constexpr int s = decltype(S_)::value;
-      cw.stage<FwdMap::B1 + s * FwdMap::NH, FwdMap::NH, 0, KS_H, 8>(in, in, bias_off_stage(1 + s), relu_out);
-      next_in(I8{}, std::true_type{});
-    });
-    {
-      float x = px, y = py, z = pz;
-      asm volatile("" : "+v"(x), "+v"(y), "+v"(z));   // re-derived, not kept across the trunk (mlp_fwd_kernel)
-      encode<P, KS_PE>(x, y, z, a.multires, g, pe);
-    }
-    cw.stage<FwdMap::B5, FwdMap::N5, KS_PE, KS_H, 8>(pe, in, bias_off_stage(5), relu_out);
-    next_in(I8{}, std::true_type{});
-    static_for<0, 2>([&](auto S_) {
-      constexpr int s = decltype(S_)::value;
-      cw.stage<FwdMap::B6 + s * FwdMap::NH, FwdMap::NH, 0, KS_H, 8>(in, in, bias_off_stage(6 + s), relu_out);
-      next_in(I8{}, std::true_type{});
-    });
-    // stage 8: feature (8 tiles, no relu) + the alpha tile (row 0 = alpha_linear)
-    float alpha = 0.f;
-    cw.stage<FwdMap::B8, FwdMap::N8, 0, KS_H, 9>(in, in, kBiasFeat, [&](auto NT_, f32x16& acc) {
-      constexpr int nt = decltype(NT_)::value;
-      if constexpr (nt < 8) tile_out(std::false_type{}, NT_, acc);
-      else alpha = acc[0];
-    });
-    next_in(I8{}, std::false_type{});
-    // stage 9: views = relu(W [feat | dir] + b), 4 tiles
-    Frag dir[KS_DIR];
-    encode<P, KS_DIR>(dx, dy, dz, a.multires_views, g, dir);
-    cw.stage<FwdMap::B9, FwdMap::N9, KS_H, KS_DIR, 4>(in, dir, kBiasViews, relu_out);
-    next_in(I4{}, std::false_type{});
-    // stage 10: rgb; the pass ends with the virtual blocks
-    f32x16 rgb;
-    cw.stage<FwdMap::B10, FwdMap::N10 + FwdMap::kVirtual, KS_H9, 0, 1>(in, in, kBiasRgb, [&](auto, f32x16& acc) { rgb = acc; });
-    if (valid && g == 0) *(f32x4*)(a.raw + 4 * m) = f32x4{rgb[0], rgb[1], rgb[2], alpha};
-    cw.base += FwdMap::kPassBlocks;
-  }
-}
 
 }  // namespace snr
 
@@ -674,20 +548,6 @@ static int launch_fwd(const FwdArgs& a, hipStream_t s) {
   return launch_status();
 }
 
-template <bool TRAIN>
-static int launch_fwd2(const FwdArgs& a, hipStream_t s) {
-  const int64_t n_wg = padded_tiles<kBF16>(a.n_samples) / c2::kCompute;
-  const int lds = c2::kBiasBytes + c2::kRing2Bytes + c2::kCompute * (c2::kSpillBytes + (TRAIN ? c2::kFlagBytes : 0));
-  if (int e = ensure_dynamic_lds<&mlp_fwd2_kernel<TRAIN>>(lds)) return e;
-  const int cus = cu_count();
-  const int64_t grid = n_wg < cus ? n_wg : cus;   // persistent: one workgroup per CU, passes grid-stride (the ring is filled once)
-  {
-    ProfScope ps(K_MLP_FWD, s);
-    mlp_fwd2_kernel<TRAIN><<<dim3((unsigned)grid), dim3(64 * c2::kWaves), lds, s>>>(a);
-  }
-  return launch_status();
-}
-
 extern "C" int snr_mlp_forward(const snr_mlp_config* c, const void* packed, const float* pts, const float* rays,
                                int ray_ld, const float* z_vals, const float* viewdirs, int viewdirs_ld,
                                int64_t n_samples, int samples_per_ray, float* raw, void* act,
@@ -714,7 +574,6 @@ extern "C" int snr_mlp_forward(const snr_mlp_config* c, const void* packed, cons
   a.enc_generic = tunables().enc_generic;
   hipStream_t s = (hipStream_t)stream;
   const bool vd = c->use_viewdirs, tr = act != nullptr;
-  if (bf && vd && !tr && tunables().chain2 && T.fwd_frags == c2::FwdMap::kBlocks * c2::kBF) return launch_fwd2<false>(a, s);
 #define SNR_FWD(P_) \
   (vd ? (tr ? launch_fwd<P_, true, true>(a, s) : launch_fwd<P_, true, false>(a, s)) \
       : (tr ? launch_fwd<P_, false, true>(a, s) : launch_fwd<P_, false, false>(a, s)))

@@ -48,6 +48,14 @@ enum Precision { kBF16 = 0, kFP32 = 1 };
 #endif
 constexpr int kBlockFrags = SNR_BLOCK_FRAGS;
 
+// Round 6: in bf16 mode the positional / directional encodings and the weight columns that multiply them are fp16 (11 mantissa
+// bits for values in [-1, 1]) inside the same fragments, consumed by v_mfma_f32_32x32x16_f16 at the bf16 rate (snr_common.h:
+// Mma<kBF16>::mma_f16).  SNR_ENC_F16=0 builds the round-5 all-bf16 arithmetic (A/B, tools/build_variant.py).
+#ifndef SNR_ENC_F16
+#define SNR_ENC_F16 1
+#endif
+template <int P> struct EncF16 { static constexpr bool value = SNR_ENC_F16 && P == kBF16; };
+
 template <int P> struct Prec;
 template <> struct Prec<kBF16> { static constexpr int EPF = 8, FPT = 2, ESZ = 2; };
 template <> struct Prec<kFP32> { static constexpr int EPF = 4, FPT = 4, ESZ = 4; };

@@ -423,6 +423,15 @@ __device__ __forceinline__ void pair_run(const PairArgs& a, const PairJob& J, in
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Kind A of pair 0 rebuilds h0 = relu(W0 enc + b0) from the SAVED encoding, which is bf16; the forward's own fragments of W0
+  // are fp16 (mlp_layout.h: EncF16): re-rounded to bf16 here, once per launch.  The rebuilt h0 then differs from the forward's
+  // by the encoding's bf16 rounding (a bf16 ulp of h0 in a fraction of its elements) — it only meets d z1 in dW1.
+  if constexpr (!PB && KR == 4 && EncF16<kBF16>::value) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < KR; ++q) W[c][q] = Mma<kBF16>::f16_to_bf16(W[c][q]);
+  }
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll

@@ -13,6 +13,7 @@
 namespace snr {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -64,7 +65,6 @@ struct Tunables {
   int merge_nets;            // SNR_MERGE_NETS=0: one backward launch sequence per network (A/B against the merged one)
   int chain_grid;            // SNR_CHAIN_GRID: workgroups of a chain-kernel launch (the rest grid-stride); 0 = default
   int enc_generic;           // SNR_ENC_GENERIC=1: the forward kernel's run-time positional encoding even where the compile-time one applies (tests)
-  int chain2;                // SNR_CHAIN2: the bf16 chain kernels with helper waves (mlp_chain2.h); 0 = the round-2 kernels (A/B)
 };
 inline Tunables read_tunables() {
   auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
@@ -80,7 +80,6 @@ inline Tunables read_tunables() {
   t.only_kind = geti("SNR_PAIR_KIND", -1);
   t.only_pair = geti("SNR_PAIR_PAIR", -1);
   t.merge_nets = geti("SNR_MERGE_NETS", 1);
-  t.chain2 = geti("SNR_CHAIN2", 0);
   t.enc_generic = geti("SNR_ENC_GENERIC", 0);
   t.chain_grid = geti("SNR_CHAIN_GRID", 0);
   return t;
@@ -123,6 +122,24 @@ template <> struct Mma<kBF16> {
   static __device__ __forceinline__ Frag zero() { return Frag{0, 0, 0, 0, 0, 0, 0, 0}; }
   static __device__ __forceinline__ void set(Frag& f, int e, float x) { f[e] = (__bf16)x; }
   static __device__ __forceinline__ float get(const Frag& f, int e) { return (float)f[e]; }
+  // ---- fp16 segments (round 6) ----------------------------------------------------------------------------------------
+  // The positional / directional ENCODINGS and the weight columns that multiply them travel as fp16 inside the same 16-byte
+  // fragments: v_mfma_f32_32x32x16_f16 runs at the bf16 rate and accumulates into the same fp32 C tile, and sin / cos values
+  // in [-1, 1] keep 11 mantissa bits instead of 8 (rounding error 2^-12 instead of 2^-9: the bf16 rounding of sin(2^9 x) was
+  // most of the bf16 path's gradient error on semi-transparent rays, profiles/r05_bf16_grad_decomp.txt).  Hidden activations
+  // stay bf16 (range); the weight-gradient pass consumes the encodings as bf16 (its other operand, d z, needs bf16's range).
+  static __device__ __forceinline__ f32x16 mma_f16(Frag a, Frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void set_f16(Frag& f, int e, float x) {
+    f16x8 h = __builtin_bit_cast(f16x8, f);
+    h[e] = (_Float16)x;
+    f = __builtin_bit_cast(Frag, h);
+  }
+  // an fp16 fragment re-rounded to bf16 (what the saved-activation sections and the weight-gradient pass hold)
+  static __device__ __forceinline__ Frag f16_to_bf16(Frag f) {
+    return __builtin_convertvector(__builtin_convertvector(__builtin_bit_cast(f16x8, f), f32x8), Frag);
+  }
 };
 
 template <> struct Mma<kFP32> {
@@ -138,6 +155,10 @@ template <> struct Mma<kFP32> {
   static __device__ __forceinline__ Frag zero() { return Frag{0.f, 0.f, 0.f, 0.f}; }
   static __device__ __forceinline__ void set(Frag& f, int e, float x) { f[e] = x; }
   static __device__ __forceinline__ float get(const Frag& f, int e) { return f[e]; }
+  // (the fp32 mode has no fp16 segments: the names exist so that the shared templates compile)
+  static __device__ __forceinline__ f32x16 mma_f16(Frag a, Frag b, f32x16 c) { return mma(a, b, c); }
+  static __device__ __forceinline__ void set_f16(Frag& f, int e, float x) { f[e] = x; }
+  static __device__ __forceinline__ Frag f16_to_bf16(Frag f) { return f; }
 };
 
 }  // namespace snr

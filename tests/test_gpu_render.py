@@ -57,6 +57,28 @@ def mostly_close(a, b, atol, rtol, frac, hard_atol, msg=""):
         assert d.max(initial=0.0) <= hard_atol, f"{msg}: max |diff| {d.max():.3e}"
 
 
+def outliers_at_most(a, b, atol, rtol, allowed, hard_max, msg=""):
+    """at most `allowed` elements outside (atol, rtol); every error within hard_max; NaNs coincide"""
+    a, b = npy(a), npy(b)
+    assert a.shape == b.shape, msg
+    nan = np.isnan(b)
+    assert np.array_equal(np.isnan(a), nan), msg
+    d = np.abs(a - b)[~nan]
+    n_out = int((d > atol + rtol * np.abs(b[~nan])).sum())
+    assert n_out <= allowed, f"{msg}: {n_out} elements outside the tolerance (this fixture measures {allowed} at most)"
+    assert d.max(initial=0.0) <= hard_max, f"{msg}: max |diff| {d.max():.3e} > {hard_max:.3e}"
+
+
+# what the fp32 path measures on every reference fixture (tests/probes/r06_fp32_gates.py on MI355X, round 6; raw lines in
+# profiles/r06_fp32_gates.jsonl)
+import json as _json
+import os as _os
+MEASURED = _json.load(open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "fp32_render_measured.json")))
+FINE_TOLS = dict(z_vals=(1e-4, 1e-5), weights=(2e-4, 0), rgb=(2e-4, 0), acc=(2e-4, 0), depth=(2e-4, 1e-3), disp=(2e-4, 1e-3),
+                 z_std=(2e-4, 1e-3))
+SURVEY_TOLS = dict(z_vals=(1e-4, 0), weights=(1e-4, 0), rgb=(1e-5, 0), acc=(1e-5, 0), depth=(1e-5, 1e-4), disp=(1e-5, 1e-4))
+
+
 def build(S, g, precision="fp32"):
     vd, och, Nf = bool(g["vd"]), int(g["och"]), int(g["Nf"])
     sd_c, sd_f = render_case_nets(g)
@@ -112,18 +134,27 @@ def test_render_forward_matches_reference(S, name, hook):
     for k in want:
         assert tuple(extras[k].shape) == g["x_" + k].shape, k
     fine = int(g["Nf"]) > 0
-    if fine:   # coarse stage: tight
-        close(extras["rgb0"], g["x_rgb0"], atol=2e-4, msg="rgb0")
-        close(extras["acc0"], g["x_acc0"], atol=2e-4, msg="acc0")
-        close(extras["disp0"], g["x_disp0"], rtol=1e-3, atol=1e-4, msg="disp0")
-        # free-running fine stage: see module docstring
-        mostly_close(extras["z_vals"], g["x_z_vals"], 1e-4, 1e-5, 0.96, None, "z_vals")
-        mostly_close(extras["weights"], g["x_weights"], 2e-4, 0, 0.98, 0.5, "weights")
-        mostly_close(rgb, g["rgb"], 2e-4, 0, 0.90, 1e-2, "rgb")
-        mostly_close(acc, g["acc"], 2e-4, 0, 0.98, 1e-2, "acc")
-        mostly_close(depth, g["depth"], 2e-4, 1e-3, 0.90, 5e-2, "depth")
-        mostly_close(disp, g["disp"], 2e-4, 1e-3, 0.85, None, "disp")
-        mostly_close(extras["z_std"], g["x_z_std"], 2e-4, 1e-3, 0.80, None, "z_std")
+    if fine:
+        M = MEASURED[name]
+        # coarse stage (no resampling upstream): 1.5 x what this fixture measures (tests/probes/r06_fp32_gates.py; the arithmetic
+        # is deterministic — profiles/r06_determinism.txt — so the measurement is what every box computes).  The wild fixtures
+        # (raw of +-7 through 2^9-frequency encodings) sit at 1e-5 ... 9e-5 against SURVEY 8(d)'s 1e-5; the networks the
+        # reference trained at 3e-7.
+        c = M["coarse"]
+        close(extras["rgb0"], g["x_rgb0"], atol=max(1.5 * c["rgb0"], 2e-6), rtol=0, msg="rgb0")
+        close(extras["acc0"], g["x_acc0"], atol=max(1.5 * c["acc0"], 2e-6), rtol=0, msg="acc0")
+        close(extras["disp0"], g["x_disp0"], rtol=max(1.5 * c["disp0_rel"], 2e-6), atol=1e-7, msg="disp0")
+        # free-running fine stage (module docstring): the number of elements outside the tolerance is held to THIS fixture's
+        # measured count (x 1.5, at least + 2), at the tolerances of rounds 1-5 ("fine") and at SURVEY 8(d)'s own
+        # ("fine_survey": rgb / acc 1e-5, depth / disp rtol 1e-4, weights / z 1e-4); the largest error to 2 x the measured one
+        got = dict(z_vals=extras["z_vals"], weights=extras["weights"], rgb=rgb, acc=acc, depth=depth, disp=disp, z_std=extras["z_std"])
+        ref = dict(z_vals=g["x_z_vals"], weights=g["x_weights"], rgb=g["rgb"], acc=g["acc"], depth=g["depth"], disp=g["disp"],
+                   z_std=g["x_z_std"])
+        for block, tols in (("fine", FINE_TOLS), ("fine_survey", SURVEY_TOLS)):
+            for k, (atol, rtol) in tols.items():
+                m = M[block][k]
+                allowed = max(int(np.ceil(1.5 * m["n_out"])), m["n_out"] + 2) if m["n_out"] else 0
+                outliers_at_most(got[k], ref[k], atol, rtol, allowed, 2.0 * m["max"] + 1e-6, f"{block} {k}")
     else:
         close(rgb, g["rgb"], atol=2e-5); close(acc, g["acc"], atol=2e-5)
         close(depth, g["depth"], rtol=1e-4, atol=2e-5); close(disp, g["disp"], rtol=1e-4, atol=2e-5)
@@ -151,7 +182,8 @@ def test_free_running_errors_are_attributed_to_displaced_samples(S, name):
     zr = g["x_z_vals"].reshape(n, -1)
     dz = np.abs(npy(ex["z_vals"]).reshape(n, -1) - zr).max(-1)
     tight = dz <= 2e-6 * np.maximum(1.0, np.abs(zr).max(-1))
-    assert tight.mean() >= 0.25, f"only {tight.mean() * 100:.1f}% of the rays reproduce the reference's z_vals to the last bits"
+    floor = MEASURED[name]["rays_with_identical_z"]["n"] - 2      # measured per fixture: 20 ... 45 of 48 rays (53 of 120)
+    assert tight.sum() >= floor, f"only {tight.sum()} of {n} rays reproduce the reference's z_vals to the last bits (measured: {floor + 2})"
     ref_disp = g["disp"].reshape(n)
     errs = {
         "rgb": (np.abs(npy(rgb).reshape(n, 3) - g["rgb"].reshape(n, 3)).max(-1), 5e-5, 10.0),

@@ -82,7 +82,13 @@ def test_render_path_frames_dumps_and_patches(tmp_path):
     # frame 0 against the reference-generated fixture (free-running gate of test_gpu_render.py: a few %
     # of the pixels may sit on an ill-conditioned resampling bin)
     ref = g["rgb"].reshape(H, W, 3)
-    assert np.mean(np.abs(rgbs[0] - ref) > 1e-4) < 0.05
+    # measured (tests/golden/fp32_render_measured.json: render_path_frame0): 11 of 360 values past 1e-4, 24 past 1e-5, the
+    # largest 5.0e-3 — gates = 1.5 x the counts, 2 x the maximum
+    import json
+    m = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp32_render_measured.json")))["render_path_frame0"]
+    d = np.abs(rgbs[0] - ref)
+    assert int((d > 1e-4).sum()) <= int(np.ceil(1.5 * m["over_1e4"])) and int((d > 1e-5).sum()) <= int(np.ceil(1.5 * m["over_1e5"]))
+    assert float(d.max()) <= 2.0 * m["max"]
 
     # patch mode with gradients: a len1 x len2 window whose corner lies in the mask's bounding box; perturb=0 and
     # raw_noise_std=0 in this case, so the patch equals the same window of the full frame
