@@ -129,6 +129,41 @@ class RenderTrainer:
         self.apply_gradients()
         return loss, rgb.detach()
 
+    def _backward_two(self, h, net_c, net_f):
+        """Both networks' parameter gradients of a fused forward, and the start of their exchange between data-parallel ranks.
+        The gradients are halves of ONE buffer.  Three ways to exchange them (tools/scale_matrix.py measures all three):
+          default                  both backward passes as one launch sequence (snr_mlp_backward_multi), then ONE all-reduce of
+                                   the 4.77 MB — the cheapest launch structure, the whole collective exposed;
+          SNR_SPLIT_ALLREDUCE=1    the same launch sequence, one all-reduce per network (started by apply_gradients);
+          SNR_OVERLAP_ALLREDUCE=1  the fine network's backward first, its all-reduce started at once, the coarse network's
+                                   backward UNDER it (two launch sequences: ~0.05 ms more kernels per step), then the coarse
+                                   network's 2.4 MB — half the bytes exposed.
+        Which wins at 8 ranks depends on the collective's latency over xGMI, unmeasured so far."""
+        n_c = net_c.flat.numel()
+        g_both = torch.empty(n_c + net_f.flat.numel(), device=net_c.flat.device, dtype=net_c.flat.dtype)
+        g_c, g_f = g_both[:n_c], g_both[n_c:]
+        if os.environ.get("SNR_OVERLAP_ALLREDUCE") == "1":
+            # (the launch structure follows the switch with or without ranks, so that a one-rank run of it is the bit-exact
+            #  reference of the collective run: tests/test_gpu_nccl_one_rank.py)
+            if self._dist:
+                import torch.distributed as dist
+            ops.fused_backward(h, g_c, g_f, passes=ops.PASS_FINE)
+            net_f.flat.grad = g_f
+            if self._dist:
+                self._works[self.nets.index(net_f)] = dist.all_reduce(g_f, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            ops.fused_backward(h, g_c, g_f, passes=ops.PASS_COARSE)
+            net_c.flat.grad = g_c
+            if self._dist:
+                self._works[self.nets.index(net_c)] = dist.all_reduce(g_c, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            return
+        ops.fused_backward(h, g_c, g_f)
+        net_f.flat.grad = g_f
+        net_c.flat.grad = g_c
+        if self._dist and os.environ.get("SNR_SPLIT_ALLREDUCE") != "1":
+            import torch.distributed as dist
+            work = dist.all_reduce(g_both, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._works[self.nets.index(net_c)] = self._works[self.nets.index(net_f)] = work
+
     # ---- the autograd-free step ------------------------------------------------------------------------------------
     def _direct_ok(self, batch_rays, chunk, extra):
         from .nerf import NeRF
@@ -172,16 +207,7 @@ class RenderTrainer:
                 # both backward passes as ONE launch sequence (snr_mlp_backward_multi: one chain launch, one weight-gradient
                 # launch, one reduce for the two networks); the two gradients are halves of one buffer, so that data-parallel
                 # ranks exchange them with a single all-reduce
-                n_c = net_c.flat.numel()
-                g_both = torch.empty(n_c + net_f.flat.numel(), device=net_c.flat.device, dtype=net_c.flat.dtype)
-                g_c, g_f = g_both[:n_c], g_both[n_c:]
-                ops.fused_backward(h, g_c, g_f)
-                net_f.flat.grad = g_f
-                net_c.flat.grad = g_c
-                if self._dist and os.environ.get("SNR_SPLIT_ALLREDUCE") != "1":
-                    import torch.distributed as dist
-                    work = dist.all_reduce(g_both, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                    self._works[self.nets.index(net_c)] = self._works[self.nets.index(net_f)] = work
+                self._backward_two(h, net_c, net_f)
             else:
                 g_c = torch.empty_like(net_c.flat.data)
                 ops.fused_backward(h, g_c)
@@ -492,16 +518,7 @@ class RenderTrainer:
                               randoms=rnd, prepare=prep, loss_terms=terms, guard_term=2)
         self._draws += 4
         if two:
-            n_c = net_c.flat.numel()
-            g_both = torch.empty(n_c + net_f.flat.numel(), device=net_c.flat.device, dtype=net_c.flat.dtype)
-            g_c, g_f = g_both[:n_c], g_both[n_c:]
-            ops.fused_backward(h, g_c, g_f)
-            net_f.flat.grad = g_f
-            net_c.flat.grad = g_c
-            if self._dist and os.environ.get("SNR_SPLIT_ALLREDUCE") != "1":
-                import torch.distributed as dist
-                work = dist.all_reduce(g_both, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                self._works[self.nets.index(net_c)] = self._works[self.nets.index(net_f)] = work
+            self._backward_two(h, net_c, net_f)
         else:
             g_c = torch.empty_like(net_c.flat.data)
             ops.fused_backward(h, g_c)

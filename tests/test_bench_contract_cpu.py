@@ -92,3 +92,23 @@ def test_bench_gpus_n_without_a_launcher_starts_n_ranks_and_fails_loudly_when_th
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "a rank failed" in r.stderr
+
+
+def test_scale_matrix_fails_loudly_without_gpus(tmp_path):
+    """tools/scale_matrix.py (the pre-staged 1/2/4/8-GPU x three all-reduce variants measurement): every bench.py run is a fresh
+    child; a run that fails shows as a FAILED row and a non-zero exit code, never as a missing row.  (Its working path on one
+    GPU: profiles/r06_scale_matrix_rehearsal.md, `--same-device`.)"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("covered by the rehearsal run on a GPU box")
+    out = tmp_path / "m.md"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_matrix.py"), "--gpus", "1,2", "--steps", "1", "--warmup", "0",
+                        "--out", str(out)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1
+    txt = out.read_text()
+    assert txt.count("FAILED") == 4 and "| merged | 1 |" in txt and "| overlap | 2 |" in txt and "| split | 2 |" in txt
+    assert len(open(str(out)[:-3] + ".jsonl").read().splitlines()) == 4

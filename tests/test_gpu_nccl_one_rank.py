@@ -25,9 +25,12 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
 res = {}
 for force in ("1", "0"):
-    for split in ("0", "1"):
+    for split in ("0", "1", "overlap"):
         os.environ["SNR_FORCE_COLLECTIVES"] = force
-        os.environ["SNR_SPLIT_ALLREDUCE"] = split
+        os.environ["SNR_SPLIT_ALLREDUCE"] = "1" if split == "1" else "0"
+        # round 6: the fine network's all-reduce under the coarse network's backward (two launch sequences; compared with the
+        # one-rank run of the SAME launch structure)
+        os.environ["SNR_OVERLAP_ALLREDUCE"] = "1" if split == "overlap" else "0"
         train, kw, nets, hwf, rays, target, rnd = _setup("mlp")
         tr = train.RenderTrainer(kw, lrate=5e-4, world_size=1)
         assert tr._dist == (force == "1")
@@ -41,12 +44,15 @@ for force in ("1", "0"):
                                   (torch.rand(n, generator=torch.Generator().manual_seed(1)) * 0.3 + 0.1).cuda(), randoms=rr)
         torch.cuda.synchronize()
         res[(force, split)] = (float(loss), float(l2), [x.flat.detach().clone() for x in nets])
-base = res[("0", "0")]
 for key, (l, l2, params) in res.items():
+    base = res[("0", "overlap" if key[1] == "overlap" else "0")]
     # (the loss VALUE is a sum of per-workgroup atomics: its last bits depend on their order; the parameters do not)
     assert abs(l - base[0]) < 1e-6 * abs(base[0]) and abs(l2 - base[1]) < 1e-6 * abs(base[1]), (key, l, base[0], l2, base[1])
     for a, b in zip(params, base[2]):
         assert torch.equal(a, b), key
+# ... and the two launch structures agree to the split-K partition of the samples (DESIGN.md 4.2)
+for a, b in zip(res[("0", "overlap")][2], res[("0", "0")][2]):
+    assert float((a - b).norm() / b.norm()) < 1e-3
 dist.barrier()
 dist.destroy_process_group()
 print("NCCL_ONE_RANK_OK")
@@ -56,7 +62,7 @@ print("NCCL_ONE_RANK_OK")
 def test_nccl_backend_with_one_rank_runs_the_collective_path_and_changes_nothing():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SNR_FORCE_COLLECTIVES", "SNR_SPLIT_ALLREDUCE"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SNR_FORCE_COLLECTIVES", "SNR_SPLIT_ALLREDUCE", "SNR_OVERLAP_ALLREDUCE"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + WORKER], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "NCCL_ONE_RANK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
