@@ -65,6 +65,26 @@ def embed_dim(multires: int, i_embed: int = 0) -> int:
     return 3 if i_embed == -1 else 3 + 6 * multires
 
 
+def embed_kernel_arithmetic(x: torch.Tensor, multires: int) -> torch.Tensor:
+    """The same encoding with the ARGUMENT REDUCTION of the HIP bf16-mode kernels (spin-nerf_amd/csrc/mlp_device.h: encode /
+    encode_static): the angle goes to the hardware sine as a number of revolutions, rev = fl32(x * fl32(2^k / 2 pi)), reduced
+    to its fractional part (exact in fp32), then sin / cos of 2 pi frac.  The product's rounding is the only inexact step that
+    matters: 2^-24 of |rev| revolutions, 6e-5 rad at x = 2, k = 9 — below the bf16 rounding of the result (2e-3) by far, but
+    a quarter of an fp16 ulp (round 6: the encodings are fp16), so the emulation reproduces it; sin / cos themselves are
+    evaluated in double (the hardware instruction's own error is not modelled).  Test infrastructure for the bf16-mode
+    comparisons only: the reference's encoding is embed() above."""
+    x = x.to(torch.float32)
+    outs = [x]
+    c = torch.tensor(0.15915494309189535, dtype=torch.float32)
+    for k in range(multires):
+        sc = c * float(2.0 ** k)                       # exact scaling of the fp32 constant
+        rev = x * sc                                   # one fp32 rounding
+        fr = (rev - torch.floor(rev)).to(torch.float64)
+        outs.append(torch.sin(2.0 * math.pi * fr).to(torch.float32))
+        outs.append(torch.cos(2.0 * math.pi * fr).to(torch.float32))
+    return torch.cat(outs, -1)
+
+
 # --------------------------------------------------------------------------
 # NeRF MLP  (DS_NeRF/run_nerf_helpers.py:74-127)
 # --------------------------------------------------------------------------
@@ -179,16 +199,29 @@ def nerf_forward_bf16emu(sd, x, input_ch=63, input_ch_views=27, skips=(4,), use_
     ``enc_f16=False`` is the round-5 arithmetic (everything bf16)."""
     q = _bf16
     qe = _f16 if enc_f16 else _bf16
+    if enc_f16:
+        # weights: rounded in the forward, the gradient passes through unrounded (a cast's autograd casts the GRADIENT too, and
+        # fp16 has no range for weight gradients of 1e-6; the kernels accumulate them in fp32)
+        qw = lambda W: W + (_f16(W) - W).detach()
+    else:
+        qw = _bf16
     input_pts, input_views = torch.split(x, [input_ch, input_ch_views], dim=-1)
+    if enc_f16:
+        # the kernels re-derive the encodings from the raw coordinates (the first three columns of an embedding,
+        # helpers:31-33) with their own argument reduction: reproduce it (embed_kernel_arithmetic)
+        if input_ch > 3 and (input_ch - 3) % 6 == 0:
+            input_pts = embed_kernel_arithmetic(input_pts[..., :3], (input_ch - 3) // 6)
+        if input_ch_views > 3 and (input_ch_views - 3) % 6 == 0:
+            input_views = embed_kernel_arithmetic(input_views[..., :3], (input_ch_views - 3) // 6)
     input_pts, input_views = qe(input_pts), qe(input_views)
     D = len([k for k in sd if k.startswith("pts_linears.") and k.endswith(".weight")])
     h = input_pts
     for i in range(D):
         W = sd[f"pts_linears.{i}.weight"]
         if i == 0:
-            Wq = qe(W)
+            Wq = qw(W)
         elif (i - 1) in skips:                      # input = cat([input_pts, h]) (helpers:110-111)
-            Wq = torch.cat([qe(W[:, :input_ch]), q(W[:, input_ch:])], -1)
+            Wq = torch.cat([qw(W[:, :input_ch]), q(W[:, input_ch:])], -1)
         else:
             Wq = q(W)
         h = q(F.relu(F.linear(h, Wq, sd[f"pts_linears.{i}.bias"])))
@@ -200,7 +233,7 @@ def nerf_forward_bf16emu(sd, x, input_ch=63, input_ch_views=27, skips=(4,), use_
         h = torch.cat([feature, input_views], -1)
         Wv = sd["views_linears.0.weight"]
         nv = Wv.shape[1] - input_ch_views           # input = cat([feature, input_views]) (helpers:119)
-        Wvq = torch.cat([q(Wv[:, :nv]), qe(Wv[:, nv:])], -1)
+        Wvq = torch.cat([q(Wv[:, :nv]), qw(Wv[:, nv:])], -1)
         h = q(F.relu(F.linear(h, Wvq, sd["views_linears.0.bias"])))
         rgb = F.linear(h, q(sd["rgb_linear.weight"]), sd["rgb_linear.bias"])
         return torch.cat([rgb, alpha], -1)

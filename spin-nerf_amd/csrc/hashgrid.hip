@@ -413,6 +413,9 @@ __global__ __launch_bounds__(64 * kHgWaves) void hg_bwd_kernel(HgTable T, const 
 #pragma unroll
     for (int q = 0; q < 4; ++q) denc = M::mma(wf(F_S1T + q), dh1[q], denc);
 
+#ifndef SNR_HG_ABLATE
+#define SNR_HG_ABLATE 0   // timing experiments (results are garbage; tools/build_variant.py): 1 no table scatter at all, 2 none for the
+#endif                    // dense levels, 4 no merge rounds, 8 no fragment stores, 16 no scatter for the hashed levels
     // ---- scatter into the table gradient ----
     // Device-scope fp32 atomics (the table gradient is shared by all XCDs: agent scope, performed at the memory side).
     // The 32 samples of a tile are consecutive samples of one ray, so at the coarse levels they fall into a handful of
@@ -441,11 +444,24 @@ __global__ __launch_bounds__(64 * kHgWaves) void hg_bwd_kernel(HgTable T, const 
           const uint32_t k_lo = (uint32_t)(int)fx | ((uint32_t)(int)fy << 21);
           const uint32_t k_hi = ((uint32_t)(int)fy >> 11) | ((uint32_t)(int)fz << 10);
           bool active = valid;
+#if SNR_HG_ABLATE & 1
+          active = false;
+#endif
+#if SNR_HG_ABLATE & 2
+          if (!L.hashed) active = false;
+#endif
+#if SNR_HG_ABLATE & 16
+          if (L.hashed) active = false;
+#endif
           // consecutive samples of a ray are neighbouring lanes: when no lane shares its cell with the lane before it
           // (the fine levels), there is nothing to merge and the leader rounds would be wasted
           const bool dup = k_lo == (uint32_t)__shfl_up((int)k_lo, 1, 64) && k_hi == (uint32_t)__shfl_up((int)k_hi, 1, 64) &&
                            (lane & 31) != 0;
-          const int rounds = __ballot(dup && valid) ? kMerge : 0;
+#if SNR_HG_ABLATE & 4
+          const int rounds = 0;
+#else
+          const int rounds = __ballot(dup && active) ? kMerge : 0;
+#endif
           for (int it = 0; it < rounds; ++it) {
             const unsigned long long bal = __ballot(active);
             if (bal == 0) break;                                   // wave-uniform
@@ -491,6 +507,7 @@ __global__ __launch_bounds__(64 * kHgWaves) void hg_bwd_kernel(HgTable T, const 
     }
 
     // ---- fragments for the weight-gradient pass ----
+#if !(SNR_HG_ABLATE & 8)
 #pragma unroll
     for (int f = 0; f < 2; ++f) { store(HgWs::K_ENC, 2, tile, f, A.enc[f]); store(HgWs::K_INC, 2, tile, f, A.inc[f]); }
 #pragma unroll
@@ -502,6 +519,7 @@ __global__ __launch_bounds__(64 * kHgWaves) void hg_bwd_kernel(HgTable T, const 
     }
     store(HgWs::K_DOUTS, 1, tile, 0, douts);
     store(HgWs::K_DRGB, 1, tile, 0, drgb);
+#endif
   }
 }
 
