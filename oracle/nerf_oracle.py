@@ -188,6 +188,21 @@ def _f16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.float16).to(torch.float32)
 
 
+class _EncLinear(torch.autograd.Function):
+    """y = enc16 W^T: the forward multiplies the fp16 encoding, the weight gradient is taken against its bf16 re-rounding — what
+    the HIP path does (the saved encodings are bf16: the weight-gradient pass pairs them with d z, which needs bf16's range).
+    No gradient to the encoding."""
+    @staticmethod
+    def forward(ctx, enc16, W):
+        ctx.save_for_backward(_bf16(enc16))
+        return enc16 @ W.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        (encbf,) = ctx.saved_tensors
+        return None, g.t() @ encbf
+
+
 def nerf_forward_bf16emu(sd, x, input_ch=63, input_ch_views=27, skips=(4,), use_viewdirs=True, enc_f16=True):
     """Same network with the HIP bf16 kernel's rounding points emulated: weights and
     every MFMA *input* activation rounded to bf16, accumulation / bias / ReLU in fp32.
@@ -216,25 +231,27 @@ def nerf_forward_bf16emu(sd, x, input_ch=63, input_ch_views=27, skips=(4,), use_
     input_pts, input_views = qe(input_pts), qe(input_views)
     D = len([k for k in sd if k.startswith("pts_linears.") and k.endswith(".weight")])
     h = input_pts
+    def enc_lin(enc, W):          # the encoding segment of a layer
+        return _EncLinear.apply(enc, qw(W)) if enc_f16 else F.linear(enc, q(W))
     for i in range(D):
         W = sd[f"pts_linears.{i}.weight"]
+        b = sd[f"pts_linears.{i}.bias"]
         if i == 0:
-            Wq = qw(W)
+            z = enc_lin(input_pts, W) + b
         elif (i - 1) in skips:                      # input = cat([input_pts, h]) (helpers:110-111)
-            Wq = torch.cat([qw(W[:, :input_ch]), q(W[:, input_ch:])], -1)
+            z = enc_lin(input_pts, W[:, :input_ch]) + F.linear(h, q(W[:, input_ch:]), b)
         else:
-            Wq = q(W)
-        h = q(F.relu(F.linear(h, Wq, sd[f"pts_linears.{i}.bias"])))
-        if i in skips:
-            h = torch.cat([input_pts, h], -1)
+            z = F.linear(h, q(W), b)
+        h = q(F.relu(z))
     if use_viewdirs:
         alpha = F.linear(h, q(sd["alpha_linear.weight"]), sd["alpha_linear.bias"])
         feature = q(F.linear(h, q(sd["feature_linear.weight"]), sd["feature_linear.bias"]))
-        h = torch.cat([feature, input_views], -1)
         Wv = sd["views_linears.0.weight"]
         nv = Wv.shape[1] - input_ch_views           # input = cat([feature, input_views]) (helpers:119)
-        Wvq = torch.cat([q(Wv[:, :nv]), qw(Wv[:, nv:])], -1)
-        h = q(F.relu(F.linear(h, Wvq, sd["views_linears.0.bias"])))
+        z = F.linear(feature, q(Wv[:, :nv]), sd["views_linears.0.bias"])
+        if input_ch_views > 0:
+            z = z + enc_lin(input_views, Wv[:, nv:])
+        h = q(F.relu(z))
         rgb = F.linear(h, q(sd["rgb_linear.weight"]), sd["rgb_linear.bias"])
         return torch.cat([rgb, alpha], -1)
     return F.linear(h, q(sd["output_linear.weight"]), sd["output_linear.bias"])

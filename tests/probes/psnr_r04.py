@@ -24,6 +24,15 @@ else changed, and the pooled 32-pair statistic is reported BESIDE the 16-pair on
 ROUND 5 BLOCK (decided by the round-4 review, recorded here before its run): SEED0=32 SEEDS=32 — seeds 32..63, same script,
 same statistic, no exclusions; reported per 16-pair block and pooled over all 64 pairs (profiles/r05_psnr_heldout.txt).  If the
 pooled held-out difference is below -0.1 dB at 2 standard errors, README and DESIGN section 2 say so.
+
+ROUND 6 BLOCK (recorded here before its run): round 6 changes the bf16 ARITHMETIC — the encodings and the weight columns they meet
+are fp16 (csrc/mlp_layout.h: EncF16).  The same 64 seeds (0..63) are re-run in bf16 with nothing else changed: REUSE_FP32=1
+SEED0=0 SEEDS=64.  The fp32 halves of the pairs are NOT re-run: the exact-fp32 path is unchanged and bit-reproducible
+(profiles/r06_determinism.txt), so each pair takes its fp32 numbers from the per-seed lines of profiles/r04_psnr_heldout.txt /
+r05_psnr_heldout.txt — and to hold that assumption to account, CHECK_FP32 (default seeds 0, 16, 32, 48) ARE re-run in fp32 and must
+reproduce their recorded lines to the printed precision, or the script stops.  Statistic as before: paired held-out difference
+bf16 - fp32 over ALL 64 pairs, no exclusions; beside it the paired difference new bf16 - old bf16.  Reported whatever it is
+(profiles/r06_psnr_heldout.txt).
 """
 import argparse
 import contextlib
@@ -148,10 +157,41 @@ def run(precision, seed):
     return float(np.mean(ps)), float(np.mean([view_psnr(c) for c in cams_ho])), view_psnr(cams_tr[0])
 
 
+def recorded():
+    """per-seed numbers of the earlier blocks: {seed: {"fp32": (train, heldout, cam), "bf16": (...)}}"""
+    import re
+    out = {}
+    pat = re.compile(r"seed\s+(\d+): last-500 train fp32 ([\d.]+) bf16 ([\d.]+) \| held-out \(4 views\) fp32 ([\d.]+) bf16 ([\d.]+) \| "
+                     r"training camera fp32 ([\d.]+) bf16 ([\d.]+)")
+    for f in ("r04_psnr_heldout.txt", "r05_psnr_heldout.txt"):
+        for l in open(os.path.join(ROOT, "profiles", f)):
+            m = pat.match(l.strip())
+            if m:
+                v = [float(x) for x in m.groups()[1:]]
+                out[int(m.group(1))] = {"fp32": (v[0], v[2], v[4]), "bf16": (v[1], v[3], v[5])}
+    return out
+
+
 def main():
     rows = []
+    reuse = os.environ.get("REUSE_FP32") == "1"
+    rec = recorded() if reuse else {}
+    if reuse:
+        for seed in [int(x) for x in os.environ.get("CHECK_FP32", "0,16,32,48").split(",") if x != ""]:
+            got = run("fp32", seed)
+            want = rec[seed]["fp32"]
+            ok = all(abs(a - b) < 0.0051 for a, b in zip(got, want))
+            print(f"fp32 check, seed {seed}: re-run {got[0]:.2f} {got[1]:.2f} {got[2]:.2f}  recorded {want[0]:.2f} {want[1]:.2f} {want[2]:.2f}  "
+                  f"{'reproduces' if ok else 'DIFFERS'}", flush=True)
+            if not ok:
+                raise SystemExit("the fp32 path no longer reproduces its recorded PSNR: re-run the pairs in full (REUSE_FP32=0)")
+    old_bf16 = []
     for seed in range(SEED0, SEED0 + SEEDS):
-        r = {p: run(p, seed) for p in ("fp32", "bf16")}
+        if reuse:
+            r = {"fp32": rec[seed]["fp32"], "bf16": run("bf16", seed)}
+            old_bf16.append(rec[seed]["bf16"])
+        else:
+            r = {p: run(p, seed) for p in ("fp32", "bf16")}
         rows.append(r)
         print(f"seed {seed:2d}: last-500 train fp32 {r['fp32'][0]:.2f} bf16 {r['bf16'][0]:.2f} | held-out (4 views) fp32 {r['fp32'][1]:.2f} "
               f"bf16 {r['bf16'][1]:.2f} | training camera fp32 {r['fp32'][2]:.2f} bf16 {r['bf16'][2]:.2f}", flush=True)
@@ -160,6 +200,11 @@ def main():
         print(f"{name}: fp32 {np.mean([r['fp32'][i] for r in rows]):.2f} dB, bf16 {np.mean([r['bf16'][i] for r in rows]):.2f} dB, "
               f"paired difference over ALL {len(d)} pairs {d.mean():+.3f} +- {d.std(ddof=1) / np.sqrt(len(d)):.3f} dB "
               f"(sd of a pair {d.std(ddof=1):.2f}, largest |difference| {np.abs(d).max():.2f})")
+    if old_bf16:
+        for i, name in ((1, "held-out views"), (0, "last-500 training batches")):
+            d = np.array([r["bf16"][i] - o[i] for r, o in zip(rows, old_bf16)])
+            print(f"NEW bf16 arithmetic against the recorded bf16 runs, {name}: paired difference over {len(d)} seeds {d.mean():+.3f} +- "
+                  f"{d.std(ddof=1) / np.sqrt(len(d)):.3f} dB (sd {d.std(ddof=1):.2f})")
     flips = [i for i, r in enumerate(rows) if abs(r["bf16"][1] - r["fp32"][1]) > 3.0]
     print(f"basin flips (held-out difference > 3 dB; included in the means above): {flips}")
 
