@@ -499,16 +499,11 @@ def main():
             e = pk.get(name + "_kernel")
             return None if e is None else (2 * e.get("FETCH_SIZE_KiB_per_launch", 0.0) + e.get("WRITE_SIZE_KiB_per_launch", 0.0)) * 1024
         traffic = launch_bytes(dom)
-        # bytes per step: every library kernel of the profiled command (2 x FETCH + WRITE per launch x its launches), divided by
-        # the command's steps — counted through the dominant kernel, whose launches per step are known
-        dom_n = pk.get(dom + "_kernel", {}).get("FETCH_SIZE_launches")
-        if dom_n:
-            steps_prof = dom_n / launches
-            hbm_step = sum((2 * e.get("FETCH_SIZE_KiB_per_launch", 0.0) * e.get("FETCH_SIZE_launches", 0)
-                            + e.get("WRITE_SIZE_KiB_per_launch", 0.0) * e.get("WRITE_SIZE_launches", 0)) * 1024 for e in pk.values()) / steps_prof
-        else:   # (PMC files of earlier rounds: per-launch averages only)
-            per = [(launch_bytes(k), kernels[k]["launches_per_step"]) for k in kernels if launch_bytes(k) is not None]
-            hbm_step = sum(b * n for b, n in per) if per else None
+        # bytes per step: every library kernel's per-launch average of the PMC passes (2 x FETCH + WRITE) x its launches per step of
+        # THIS run (the passes themselves run different numbers of steps — the sustained part is timed, not counted — so their
+        # launch counts are not used)
+        per = [(launch_bytes(k), kernels[k]["launches_per_step"]) for k in kernels if launch_bytes(k) is not None]
+        hbm_step = sum(b * n for b, n in per) if per else None
     roofline = {
         "kernel": dom, "bound": "mfma",
         "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kernels[dom]["tflops"] / peak,

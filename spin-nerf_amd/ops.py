@@ -9,6 +9,18 @@ from . import _lib
 from ._lib import check, f32c, ptr, stream
 
 
+def _req(t, numel, dev, what):
+    """The kernels take raw device pointers: a tensor on another device, or with fewer elements than the kernel will read, is a
+    fault or a silent out-of-bounds read there — so it is an error HERE (the reference's torch ops raise for the same inputs).
+    ``t`` None passes (optional operands)."""
+    if t is None:
+        return
+    if t.device != dev:
+        raise ValueError(f"{what}: expected a tensor on {dev}, got {t.device}")
+    if t.numel() != numel:
+        raise ValueError(f"{what}: expected {numel} elements, got {tuple(t.shape)}")
+
+
 # ----------------------------------------------------------------------------------------------
 # stratified sampling (run_nerf.py:646-668)
 # ----------------------------------------------------------------------------------------------
@@ -19,6 +31,7 @@ def sample_coarse(ray_batch, N_samples, lindisp=False, t_rand=None):
     n = rays.shape[0]
     z = torch.empty(n, N_samples, device=rays.device, dtype=torch.float32)
     tr = f32c(t_rand) if t_rand is not None else None
+    _req(tr, n * N_samples, rays.device, "sample_coarse: t_rand")
     check(lib.snr_sample_coarse(ptr(rays), rays.shape[1], n, N_samples, int(bool(lindisp)), ptr(tr), ptr(z),
                                 stream()), "snr_sample_coarse")
     return z
@@ -37,6 +50,8 @@ def sample_fine(z_coarse, weights, N_importance, u=None):
     z_s = torch.empty(n, N_importance, device=zc.device, dtype=torch.float32)
     z_std = torch.empty(n, device=zc.device, dtype=torch.float32)
     uu = f32c(u) if u is not None else None
+    _req(w, n * nc, zc.device, "sample_fine: weights")
+    _req(uu, n * N_importance, zc.device, "sample_fine: u")
     check(lib.snr_sample_fine(ptr(zc), ptr(w), ptr(uu), n, nc, N_importance, ptr(z_out), ptr(z_s), ptr(z_std),
                               stream()), "snr_sample_fine")
     return z_out, z_s, z_std
@@ -65,6 +80,8 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
             u = torch.rand(n, N_samples, device=b.device)
     uc = f32c(u) if u is not None else None
     out = torch.empty(n, N_samples, device=b.device, dtype=torch.float32)
+    _req(w, n * (b.shape[1] - 1), b.device, "sample_pdf: weights")
+    _req(uc, n * N_samples, b.device, "sample_pdf: u")
     check(lib.snr_sample_pdf(ptr(b), ptr(w), ptr(uc), n, b.shape[1], N_samples, ptr(out), stream()), "snr_sample_pdf")
     return out
 
@@ -83,6 +100,10 @@ class _Composite(torch.autograd.Function):
         w = torch.empty(n, S, device=dev)
         alpha = torch.empty(n, S, device=dev) if need_alpha else None
         nz = f32c(noise) if noise is not None else None
+        _req(z, n * S, dev, "raw2outputs: z_vals")
+        _req(nz, n * S, dev, "raw2outputs: noise")
+        if r.device != dev or r.dim() != 2 or r.shape[0] != n or r.shape[1] < 6:
+            raise ValueError(f"raw2outputs: rays must be [{n}, >= 6] on {dev}, got {tuple(r.shape)} on {r.device}")
         check(lib.snr_composite_forward(ptr(raw_c), C, ptr(z), ptr(r), r.shape[1], ptr(nz), n, S,
                                         int(bool(white_bkgd)), ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(w),
                                         ptr(alpha), stream()), "snr_composite_forward")
@@ -141,6 +162,10 @@ class _CompositeAlpha(torch.autograd.Function):
         dev = raw_c.device
         rgb = torch.empty(n, 3, device=dev); disp = torch.empty(n, device=dev); acc = torch.empty(n, device=dev)
         depth = torch.empty(n, device=dev); w = torch.empty(n, S, device=dev)
+        _req(a, n * S, dev, "composite from alpha: alpha")
+        _req(z, n * S, dev, "composite from alpha: z_vals")
+        if r.device != dev or r.dim() != 2 or r.shape[0] != n or r.shape[1] < 6:
+            raise ValueError(f"composite from alpha: rays must be [{n}, >= 6] on {dev}, got {tuple(r.shape)} on {r.device}")
         check(lib.snr_composite_alpha_forward(ptr(raw_c), C, ptr(z), ptr(r), r.shape[1], ptr(a), n, S, int(bool(white_bkgd)),
                                               ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(w), stream()),
               "snr_composite_alpha_forward")
@@ -266,6 +291,8 @@ def mse_pair(a, b, target):
     loss = torch.empty(2, device=a_c.device, dtype=torch.float32)
     ga = torch.empty_like(a_c)
     gb = torch.empty_like(b_c) if b_c is not None else None
+    _req(t_c, a_c.numel(), a_c.device, "mse_pair: target")
+    _req(b_c, a_c.numel(), a_c.device, "mse_pair: second map")
     check(lib.snr_mse_pair(ptr(a_c), ptr(b_c), ptr(t_c), a_c.numel(), ptr(loss), ptr(ga), ptr(gb), stream()),
           "snr_mse_pair")
     return loss[0], loss[1], ga, gb
@@ -348,6 +375,17 @@ def mlp_query(net, pts=None, rays=None, z_vals=None, viewdirs=None, samples_per_
             viewdirs = f32c(viewdirs)
     else:
         viewdirs = None
+    # raw pointers from here on: shapes and devices the kernel will assume
+    dev = net.flat.device
+    n_rays = -(-M // max(int(samples_per_ray), 1))
+    if pts is not None:
+        if pts.device != dev or pts.dim() != 2 or pts.shape[1] != 3:
+            raise ValueError(f"mlp_query: pts must be [M, 3] on {dev}, got {tuple(pts.shape)} on {pts.device}")
+    else:
+        if rays.device != dev or z_vals.device != dev or rays.dim() != 2 or rays.shape[0] != z_vals.shape[0] or rays.shape[1] < 6:
+            raise ValueError(f"mlp_query: rays [N, >= 6] and z_vals [N, S] on {dev} expected, got {tuple(rays.shape)} / {tuple(z_vals.shape)}")
+    if viewdirs is not None and (viewdirs.device != dev or viewdirs.dim() != 2 or viewdirs.shape[0] < n_rays or viewdirs.shape[1] < 3):
+        raise ValueError(f"mlp_query: viewdirs must be [>= {n_rays}, >= 3] on {dev}, got {tuple(viewdirs.shape)} on {viewdirs.device}")
     # Function.forward always runs with grad mode off, and needs_input_grad stays True under torch.no_grad(): a detached
     # buffer is what tells it that this evaluation saves nothing (inference kernel, no activation workspace)
     flat = net.flat if torch.is_grad_enabled() else net.flat.detach()
@@ -384,6 +422,13 @@ def composite_train(raw, z_vals, rays, target, loss, loss_also=None, noise=None,
     dev = raw.device
     rgb = torch.empty(n, 3, device=dev); disp = torch.empty(n, device=dev); acc = torch.empty(n, device=dev)
     depth = torch.empty(n, device=dev); w = torch.empty(n, S, device=dev); d_raw = torch.empty_like(raw)
+    _req(z_vals, n * S, dev, "composite_train: z_vals")
+    _req(target, 3 * n, dev, "composite_train: target")
+    _req(noise, n * S, dev, "composite_train: noise")
+    _req(loss, loss.numel(), dev, "composite_train: loss")
+    _req(loss_also, loss_also.numel() if loss_also is not None else 0, dev, "composite_train: loss_also")
+    if rays.device != dev or rays.shape[0] != n:
+        raise ValueError(f"composite_train: rays must have {n} rows on {dev}")
     check(lib.snr_composite_train(ptr(raw), C, ptr(z_vals), ptr(rays), rays.shape[1], ptr(noise), float(noise_std),
                                   int(seed), int(offset), n, S, int(bool(white_bkgd)), int(bool(detach_weights)),
                                   ptr(target), n, ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(w), ptr(d_raw), ptr(loss),
