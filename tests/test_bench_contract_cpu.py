@@ -40,6 +40,16 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1
+    # round 6: the rate is shown to hold for seconds, the frame has a roofline of its own, the CPU baseline
+    # is reported at the best thread count AND at os.cpu_count()
+    s = d["sustained"]
+    assert s["seconds"] >= 2.5 and s["steps"] >= d["steps"] and abs(s["ms_per_step"] - s["seconds"] / s["steps"] * 1e3) < 1e-9
+    assert abs(s["ratio_to_ms_per_step"] - s["ms_per_step"] / d["ms_per_step"]) < 1e-9 and s["holds"] == (s["ratio_to_ms_per_step"] <= 1.03)
+    f = d["frame_roofline"]
+    assert f["bound"] == "mfma" and abs(f["flops_per_frame"] - 57.88e12) < 0.01e12 and abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-9
+    assert abs(f["achieved"] - f["flops_per_frame"] / (d["ms_per_frame_378x504"] * 1e-3) / 1e12) < 1e-6 * f["achieved"]
+    a = c["all_cores"]
+    assert a["cores"] >= c["cores"] and a["unit"] == c["unit"] and a["value"] > 0
 
 
 def test_every_kernels_key_of_the_bench_line_is_a_kernel_of_the_rocprofv3_trace():
