@@ -160,8 +160,6 @@ def main():
     ap.add_argument("--n-fine", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--blocks", type=int, default=5, help="back-to-back timed blocks of --steps steps; the median block is reported")
-    ap.add_argument("--preheat-s", type=float, default=float(os.environ.get("SNR_BENCH_PREHEAT_S", "1.5")),
-                    help="seconds of no-grad frame renders before the warm-up steps (0 = off)")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="seconds of continuous steps behind the timed blocks (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frame", action="store_true")
@@ -232,23 +230,6 @@ def main():
             rays, target = batches[(first + i) % n_batches]
             trainer.step(H, W, focal, rays, target)
 
-    # Pre-heat (round 6): the blocks of a fresh process read ~4 % slower than the same steps sustained for seconds — per step,
-    # whatever the block length (20 or 50 steps), i.e. not a per-block ramp but the device's clock governor settling under load
-    # (profiles/r06_preheat_ab.txt).  The reference's metric is the STEADY-STATE rate, so the device is brought
-    # there first with no-grad frame renders — not training steps: the W warm-up steps and the K timed steps below are exactly
-    # what the command line says — for --preheat-s seconds (0 = off; reported in the line as `preheat`).
-    preheat = None
-    if ns.preheat_s > 0:
-        c2w_p = torch.eye(4)[:3, :4].to(device)
-        tp = time.perf_counter()
-        n_pre = 0
-        with torch.no_grad():
-            while time.perf_counter() - tp < ns.preheat_s:
-                S.render(H, W, focal, chunk=1024 * 32, c2w=c2w_p, **kw_test)
-                torch.cuda.synchronize()
-                n_pre += 1
-        preheat = {"seconds": time.perf_counter() - tp, "frames": n_pre,
-                   "what": "no-grad 378x504 frame renders in front of the warm-up steps (device clock settles under load); --preheat-s 0 turns it off"}
     # W untimed warm-up steps, then R back-to-back blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both
     # sides and reduced with MAX over the ranks; the MEDIAN block is the reported step time (one 20-step block is a 20 ms
     # sample: bimodal at +-2 % and invisible to a 5 s SMI sampler — VERDICT r02), all blocks are listed in `block_ms`
@@ -593,7 +574,6 @@ def main():
             "frac": 2.0 * MAC_FWD * H * W * (ns.n_coarse + (ns.n_coarse + ns.n_fine if ns.n_fine else 0)) / (ms_frame * 1e-3) / 1e12 / PEAK_TFLOPS[ns.precision],
             "frames_timed": 12},
         "sustained": sustained,
-        "preheat": preheat,
         "step_tflops_algorithmic": step_flops / (elapsed / ns.steps) / 1e12,
         "hbm_bytes_per_step": hbm_step,
         "blocks": len(block_s), "block_ms": [round(b * 1e3, 4) for b in block_s],
