@@ -278,7 +278,7 @@ def test_direct_spin_iteration_bf16_runs_on_the_merged_backward():
         assert float((n.flat.grad - gd).norm() / gd.norm()) < 6e-3
 
 
-def test_colmap_depth_render_and_prepare_export_and_lpips_hookup(tmp_path):
+def test_colmap_depth_render_and_prepare_export_and_lpips_hookup(tmp_path, monkeypatch):
     """The rest of the iteration (run_nerf.py:1473-1507, 1523-1561, 1563-1609): the render with the COLMAP `depths=` column
     and its depth loss against the oracle (loss value and gradients), the perceptual term's patch renders with a stand-in
     distance, and the --prepare disparity export."""
@@ -360,12 +360,43 @@ def test_colmap_depth_render_and_prepare_export_and_lpips_hookup(tmp_path):
         assert float(pred.detach().abs().max()) <= 1.0 + 1e-5 and float(target.abs().max()) <= 1.0 + 1e-5
         calls.append(1)
         return ((pred - target) ** 2).mean(dim=(1, 2, 3))
-    for n in (net_c, net_f):
-        n.flat.grad = None
-    term = tr.lpips_term(dist_fn, poses, images, masks, (H, W, focal), kw_test)
-    assert len(calls) == 2 and 0 < float(term.detach()) < 4.0 / 100 + 1e-6
-    term.backward()
-    assert float(net_f.flat.grad.abs().max()) > 0
+    # The patch corner is drawn with random.randint inside the mask's bounding box (run_nerf.py:197-209): X in 4..10, Y in 5..13.
+    # These untrained gain-2 networks have a density <= 0 on 433 of the 480 pixels (every fine weight exactly 0 there), so 18 of
+    # the 63 corners of pose 0 and 5 of pose 1 give an ALL-EMPTY 5 x 6 patch — whose perceptual term has, correctly, a gradient
+    # of exactly zero.  Rounds 1-5 drew the corner from the process's unseeded `random` state and asserted "gradient > 0": with
+    # both poses' patches empty (18/63 x 5/63 = 2.3 % of the draws) the assertion failed — THE intermittent failure of the full
+    # suite (round 5: once in ~25 runs; round 6: pass 18 of a 24-pass soak, full output in profiles/r06_soak.txt; the 40 seeds
+    # round 5 tried had a 40 % chance of missing it).  A defect of the test, not of a kernel.  Now every corner is visited, for
+    # both poses at once, and the property that holds is asserted: the gradient is non-zero exactly when a patch is not empty.
+    import random
+    n_empty = n_lit = 0
+
+    def acc_sum(pose, X, Y):
+        with torch.no_grad():   # acc_map = sum of the (non-negative) weights of the fine pass
+            return float(S.render(H, W, focal, chunk=1024, c2w=pose[:3, :4], patch=(X, Y, H // 4, W // 4), **kw_test)[2].abs().sum())
+    corners = [(X, Y) for X in range(4, 11) for Y in range(5, 14)]
+    # pose 0 sweeps every corner while pose 1 sits on one of ITS empty corners, then the other way round (the two poses' empty
+    # corners do not overlap: CPU oracle, 18 and 5 of 63)
+    fixed = {1: next(c for c in corners if acc_sum(poses[1], *c) == 0.0), 0: next(c for c in corners if acc_sum(poses[0], *c) == 0.0)}
+    for moving in (0, 1):
+        for c in corners:
+            pair = (c, fixed[1]) if moving == 0 else (fixed[0], c)
+            draws = iter([pair[0][0], pair[0][1], pair[1][0], pair[1][1]])     # render_path draws X then Y, pose by pose
+            monkeypatch.setattr(random, "randint", lambda a, b: next(draws))
+            lit = acc_sum(poses[moving], *c) > 0.0
+            for n in (net_c, net_f):
+                n.flat.grad = None
+            calls.clear()
+            term = tr.lpips_term(dist_fn, poses, images, masks, (H, W, focal), kw_test)
+            assert len(calls) == 2 and 0 < float(term.detach()) < 4.0 / 100 + 1e-6
+            term.backward()
+            got = float(net_f.flat.grad.abs().max()) > 0
+            assert got == lit, (f"pose {moving} at corner {c} (the other pose on an empty patch): patch {'not ' if lit else ''}empty, "
+                                f"fine-network gradient {'non-' if got else ''}zero")
+            n_empty += not lit
+            n_lit += lit
+    monkeypatch.undo()
+    assert n_empty >= 10 and n_lit >= 60, (n_empty, n_lit)   # the scene has both kinds (CPU oracle: 18 + 5 empty, 45 + 58 lit)
 
     # ---- --prepare: disparity maps and masks for the depth inpainter ----
     tr.export_disparities(poses, (H, W, focal), kw_test, masks, str(tmp_path / "prep"), render_factor=2)
