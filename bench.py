@@ -91,7 +91,7 @@ def cpu_baseline(ns, H, W, focal, near, far):
             t0 = time.perf_counter()
             O.train_step(sd_c, sd_f, opt, rays, target, kw, randoms=rnd)
             times.append(time.perf_counter() - t0)
-        return float(np.mean(times[1:]))
+        return float(np.mean(times[1:])) if steps > 0 else float(times[0])
 
     # measured on the MI355X host (256 hardware threads): torch's intra-op pool peaks at 32 threads for
     # these shapes (8: 267, 16: 273, 32: 301, 64: 177, 128: 86 rays/s)
@@ -101,12 +101,12 @@ def cpu_baseline(ns, H, W, focal, near, far):
            "sample": f"{ns.cpu_steps} steps of {n_rand} rays x ({ns.n_coarse}+{ns.n_fine}) samples after 1 warm-up, "
                      f"fp32 torch CPU ops, {best} threads of a {os.cpu_count()}-thread host, anomaly detection off"}
     if os.cpu_count() > best:
-        # (bounded: at 256 threads torch's intra-op pool collapses — a full 1024-ray step takes ~95 s there — so the all-cores
-        #  figure is taken on an eighth of the batch, one timed step after one warm-up: ~25 s)
-        n_small = max(32, n_rand // 8)
-        t_all = timed(os.cpu_count(), 1, n_small)
+        # (bounded: at 256 threads torch's intra-op pool collapses — 2 rays/s on small batches, ~11 on full ones, a full 1024-ray
+        #  step takes ~95 s — so the all-cores figure is ONE timed step on 32 rays, no warm-up of its own: ~15 s)
+        n_small = max(32, n_rand // 32)
+        t_all = timed(os.cpu_count(), 0, n_small)
         out["all_cores"] = {"value": n_small / t_all, "unit": "rays/s", "cores": os.cpu_count(),
-                            "sample": f"1 step of {n_small} rays after 1 warm-up, torch.set_num_threads(os.cpu_count())"}
+                            "sample": f"1 step of {n_small} rays, no warm-up, torch.set_num_threads(os.cpu_count())"}
     return out
 
 

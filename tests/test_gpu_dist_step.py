@@ -72,9 +72,12 @@ def _worker(rank, world, port, out, kind):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("kind", ["mlp", "hash"])
-def test_two_rank_step_equals_single_process_step_on_the_global_batch(tmp_path, kind):
+@pytest.mark.parametrize("kind", ["mlp", "hash", "mlp-overlap"])
+def test_two_rank_step_equals_single_process_step_on_the_global_batch(tmp_path, kind, monkeypatch):
     import torch.multiprocessing as mp
+    if kind == "mlp-overlap":     # round 6: the fine network's all-reduce under the coarse network's backward (train.py: _backward_two)
+        monkeypatch.setenv("SNR_OVERLAP_ALLREDUCE", "1")
+        kind = "mlp"
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "rank0.pt")
     mp.spawn(_worker, args=(2, port, out, kind), nprocs=2, join=True)
