@@ -275,3 +275,23 @@ def test_process_wide_settings_are_read_once_and_thread_safe(S, monkeypatch):
                                                    None, None, None, None, None, None, None, None, None, None, None) == -1
     assert lib.snr_render_step_prepare(ctypes.byref(rc), None, None, 8, 4, 4, 1.0, 0, 0.0, 1.0, 1, None, 11, None, 0, 0, None,
                                        None, None, None) == -1
+
+
+def test_poison_switch_wraps_the_allocation_entry_points_and_is_off_by_default():
+    """spin-nerf_amd/_debug.py (round 6): SNR_POISON_WS=1 fills every DEVICE buffer obtained through torch.empty / empty_like /
+    new_empty with 0xFF bytes before the library sees it.  Without the variable nothing is wrapped; the wrappers leave host
+    tensors alone (there is no GPU here: the fill itself is exercised by every soak pass on the GPU box)."""
+    import importlib
+    import subprocess
+    import sys
+    import torch
+    dbg = importlib.import_module("spin-nerf_amd._debug")
+    assert not dbg.poison_enabled() or os.environ.get("SNR_POISON_WS") not in (None, "", "0")
+    code = ("import os, sys, importlib, torch; sys.path.insert(0, %r); e0 = torch.empty; "
+            "d = importlib.import_module('spin-nerf_amd._debug'); "
+            "assert (torch.empty is not e0) == (os.environ.get('SNR_POISON_WS') == '1'); "
+            "t = torch.empty(4); u = torch.empty_like(t); v = t.new_empty(3); assert t.shape == (4,) and u.shape == (4,) and v.shape == (3,); "
+            "assert d.install_poison() and torch.empty is not e0; print('ok')") % ROOT
+    for val in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SNR_POISON_WS=val), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (val, r.stderr[-1500:])
